@@ -1,0 +1,137 @@
+/* librgp_hip.so -- C ABI of the MI355X-native recurrent gaze-prediction path.
+ *
+ * The reference (yj-yu/Recurrent_Gaze_Prediction) has no FFI/plugin boundary: its
+ * seam is the Python graph builder `create_gazeprediction_network(frame_images,
+ * c3d_input, dropout_keep_prob, net)` (models/gaze_grcn.py:173-188) executed by a
+ * single `session.run(feed_dict)` (models/gaze_rnn.py:523-531, 603-611).  This
+ * header is the boundary a maintainer would bind in its place: each entry point
+ * cites the reference lines whose computation it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 (RGP_OK) or a negative RGP_E* code; the message is in
+ *    rgp_last_error() (thread-local);
+ *  - every tensor argument is a caller-owned DEVICE pointer (fp32 unless stated);
+ *    the library never allocates device memory: the caller provides one workspace
+ *    of rgp_*_workspace_bytes() bytes per plan;
+ *  - every call is asynchronous on the given HIP stream (a hipStream_t passed as
+ *    void*); a plan may be used from one stream at a time;
+ *  - layouts are the reference's: c3d_input [B,T,1024,7,7], maps [B,T,49,49],
+ *    conv filters HWIO / DHWIO, transposed-conv filters [kh,kw,out,in];
+ *  - dtype selects the MFMA operand type of the contractions (RGP_BF16:
+ *    v_mfma_f32_16x16x32_bf16, RGP_F32: v_mfma_f32_16x16x4_f32); accumulation,
+ *    gate math, recurrent state, logits and losses are always fp32.
+ */
+#ifndef RGP_H_
+#define RGP_H_
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGP_OK 0
+#define RGP_EINVAL (-1)   /* bad argument / unsupported shape */
+#define RGP_EHIP (-2)     /* a HIP runtime call failed */
+#define RGP_EWORKSPACE (-3) /* workspace missing or too small */
+#define RGP_ESTATE (-4)   /* call order violated (e.g. forward before set_weights) */
+
+#define RGP_F32 0
+#define RGP_BF16 1
+
+typedef void* rgp_stream_t; /* hipStream_t */
+
+const char* rgp_last_error(void);
+int rgp_version(void);
+/* Writes the gcnArchName of the current device ("gfx950...") into buf. */
+int rgp_device_arch(char* buf, int buflen);
+
+/* ------------------------------------------------------------------ gaze_grcn */
+typedef struct rgp_grcn rgp_grcn_t;
+
+/* fp32 device pointers, reference variable names:
+ * proj_c3d_W [1024,P] proj_c3d_b [P]                    gaze_grcn.py:234-237
+ * gru_W{z,r,}  [3,3,P,S]   gru_U{z,r,} [3,3,S,S]        gaze_grcn.py:64-81
+ * bn_gamma, bn_beta [T,S] (one BN layer per timestep)   gaze_grcn.py:325
+ * up_weight1 [5,5,64,S] up_weight2 [5,5,32,64] up_weight3 [7,7,12,32]   gaze_grcn.py:292-310
+ * out_W [12,1] out_b [1]                                gaze_grcn.py:311-314 */
+typedef struct rgp_grcn_weights {
+  const float *proj_c3d_W, *proj_c3d_b;
+  const float *gru_Wz, *gru_Uz, *gru_Wr, *gru_Ur, *gru_W, *gru_U;
+  const float *bn_gamma, *bn_beta;
+  const float *up_weight1, *up_weight2, *up_weight3;
+  const float *out_W, *out_b;
+} rgp_grcn_weights;
+
+/* Plan for GazePredictionGRCN.create_gazeprediction_network (gaze_grcn.py:173-376)
+ * at fixed batch B, timesteps T, dim_cnn_proj P (512), rnn_state_size S (128). */
+int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int dim_state, int dtype,
+                    int save_for_backward);
+int rgp_grcn_destroy(rgp_grcn_t* plan);
+size_t rgp_grcn_workspace_bytes(const rgp_grcn_t* plan);
+/* Uploads the offset tables and zeroes the halos.  Once per workspace. */
+int rgp_grcn_bind_workspace(rgp_grcn_t* plan, void* workspace, size_t bytes, rgp_stream_t stream);
+/* Packs the fp32 weights into MFMA operand form ([N][K], operand dtype). Call after
+ * every weight update. */
+int rgp_grcn_set_weights(rgp_grcn_t* plan, const rgp_grcn_weights* w, rgp_stream_t stream);
+
+/* Whole graph: c3d_input [B,T,1024,7,7] -> logits [B,T,49,49]
+ * (gaze_grcn.py:173-376) and, if probs != NULL, the per-frame softmax that
+ * build_model applies for loss_type xentropy (gaze_rnn.py:149-159). */
+int rgp_grcn_forward(rgp_grcn_t* plan, const float* c3d_input, float* logits, float* probs, rgp_stream_t stream);
+/* Same graph fed by C3D conv5b rows produced by rgp_c3d_forward (operand dtype,
+ * [B*T*49][1024] with K order d*512+c), skipping the transpose of gaze_grcn.py:225-227. */
+int rgp_grcn_forward_rows(rgp_grcn_t* plan, const void* c3d_rows, float* logits, float* probs, rgp_stream_t stream);
+
+/* Stages of the same graph on the plan's workspace (for tests / profiling):
+ * rgp_proj_fwd          transpose + xw_plus_b                  gaze_grcn.py:225-254
+ * rgp_convgru_xconv_fwd W_z,W_r,W convs of all T steps at once gaze_grcn.py:108-109,112-113,122-123
+ * rgp_convgru_seq_fwd   T x { U convs, gates, blend } + BN     gaze_grcn.py:110-127,259-288,325
+ * rgp_head_fwd          3 transposed convs + 12->1             gaze_grcn.py:326-366 */
+int rgp_proj_fwd(rgp_grcn_t* plan, const float* c3d_input, rgp_stream_t stream);
+int rgp_convgru_xconv_fwd(rgp_grcn_t* plan, rgp_stream_t stream);
+int rgp_convgru_seq_fwd(rgp_grcn_t* plan, rgp_stream_t stream);
+int rgp_head_fwd(rgp_grcn_t* plan, float* logits, rgp_stream_t stream);
+
+/* Copies an intermediate, un-padded and widened to fp32, into dst:
+ * "c3d_embedded" [B,T,7,7,P]   "xpre" [B,T,7,7,3S] (z|r|c pre-activations of W*x)
+ * "rcn_outputs" [B,T,7,7,S] (h_t)   "bn" [B,T,7,7,S]   "d1" [B*T,23,23,64]   "d2" [B*T,49,49,32]
+ * "u" / "r" / "c" [T,B,7,7,S] (r,c only with save_for_backward). */
+int rgp_grcn_read_buffer(rgp_grcn_t* plan, const char* name, float* dst, rgp_stream_t stream);
+/* Number of fp32 elements rgp_grcn_read_buffer writes for name (0 if unknown). */
+size_t rgp_grcn_buffer_elems(const rgp_grcn_t* plan, const char* name);
+
+/* Per-frame softmax (model_util.py:61-64) and cross entropy with summed/averaged
+ * loss (model_util.py:66-72, gaze_rnn.py:390-407): logits, labels [frames, npix];
+ * probs, frame_loss [frames], loss [1] may each be NULL.  loss = sum(frame_loss)/frames. */
+int rgp_softmax_xent_fwd(const float* logits, const float* labels, float* probs, float* frame_loss, float* loss,
+                         int frames, int npix, rgp_stream_t stream);
+
+/* ------------------------------------------------------------------ C3D conv stack */
+typedef struct rgp_c3d rgp_c3d_t;
+
+/* conv1a..conv5b (prototxt:22-342): w[i] DHWIO [3,3,3,Cin,Cout] fp32, b[i] [Cout]. */
+typedef struct rgp_c3d_weights {
+  const float* w[8];
+  const float* b[8];
+} rgp_c3d_weights;
+
+/* Plan for up to max_windows 16x112x112x3 windows per call. */
+int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype);
+int rgp_c3d_destroy(rgp_c3d_t* plan);
+size_t rgp_c3d_workspace_bytes(const rgp_c3d_t* plan);
+int rgp_c3d_bind_workspace(rgp_c3d_t* plan, void* workspace, size_t bytes, rgp_stream_t stream);
+int rgp_c3d_set_weights(rgp_c3d_t* plan, const rgp_c3d_weights* w, rgp_stream_t stream);
+/* video [n,16,112,112,3] fp32 (mean-subtracted, channels last) -> conv5b after ReLU.
+ * features (optional): [n,1024,7,7] fp32, channel = c*2+d (gaze_rnn.py:494-497).
+ * rows (optional): [n*49][1024] in the plan's operand dtype, K order d*512+c, the
+ * form rgp_grcn_forward_rows consumes. */
+int rgp_c3d_forward(rgp_c3d_t* plan, const float* video, int n_windows, float* features, void* rows,
+                    rgp_stream_t stream);
+/* Copies layer i's (0..7) pooled, post-ReLU output, un-padded fp32 NDHWC, into dst. */
+int rgp_c3d_read_layer(rgp_c3d_t* plan, int layer, int n_windows, float* dst, rgp_stream_t stream);
+size_t rgp_c3d_layer_elems(const rgp_c3d_t* plan, int layer, int n_windows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGP_H_ */

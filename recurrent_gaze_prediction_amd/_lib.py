@@ -1,0 +1,83 @@
+"""ctypes binding of librgp_hip.so (the C ABI declared in include/rgp.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails,
+this module raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C recurrent_gaze_prediction_amd/csrc``).
+"""
+import ctypes
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librgp_hip.so')
+
+RGP_F32, RGP_BF16 = 0, 1
+DTYPES = {'f32': RGP_F32, 'fp32': RGP_F32, 'float32': RGP_F32, 'bf16': RGP_BF16, 'bfloat16': RGP_BF16}
+
+c_void_p, c_int, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p
+
+
+class RgpError(RuntimeError):
+    pass
+
+
+class GrcnWeights(ctypes.Structure):
+    FIELDS = ('proj_c3d_W', 'proj_c3d_b', 'gru_Wz', 'gru_Uz', 'gru_Wr', 'gru_Ur', 'gru_W', 'gru_U',
+              'bn_gamma', 'bn_beta', 'up_weight1', 'up_weight2', 'up_weight3', 'out_W', 'out_b')
+    _fields_ = [(n, c_void_p) for n in FIELDS]
+
+
+class C3DWeights(ctypes.Structure):
+    _fields_ = [('w', c_void_p * 8), ('b', c_void_p * 8)]
+
+
+# name -> (restype, argtypes); every symbol include/rgp.h declares
+SIGNATURES = {
+    'rgp_last_error': (c_char_p, []),
+    'rgp_version': (c_int, []),
+    'rgp_device_arch': (c_int, [c_char_p, c_int]),
+    'rgp_grcn_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
+    'rgp_grcn_destroy': (c_int, [c_void_p]),
+    'rgp_grcn_workspace_bytes': (c_size_t, [c_void_p]),
+    'rgp_grcn_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rgp_grcn_set_weights': (c_int, [c_void_p, ctypes.POINTER(GrcnWeights), c_void_p]),
+    'rgp_grcn_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rgp_grcn_forward_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rgp_proj_fwd': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'rgp_convgru_xconv_fwd': (c_int, [c_void_p, c_void_p]),
+    'rgp_convgru_seq_fwd': (c_int, [c_void_p, c_void_p]),
+    'rgp_head_fwd': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'rgp_grcn_read_buffer': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
+    'rgp_grcn_buffer_elems': (c_size_t, [c_void_p, c_char_p]),
+    'rgp_softmax_xent_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rgp_c3d_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
+    'rgp_c3d_destroy': (c_int, [c_void_p]),
+    'rgp_c3d_workspace_bytes': (c_size_t, [c_void_p]),
+    'rgp_c3d_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rgp_c3d_set_weights': (c_int, [c_void_p, ctypes.POINTER(C3DWeights), c_void_p]),
+    'rgp_c3d_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'rgp_c3d_read_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rgp_c3d_layer_elems': (c_size_t, [c_void_p, c_int, c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librgp_hip.so and bind every declared symbol.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RgpError('%s not found: the HIP extension is not built (run __graft_entry__.build()); '
+                       'there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RgpError('librgp_hip error %d: %s' % (rc, load().rgp_last_error().decode()))

@@ -1,0 +1,392 @@
+// Implicit-GEMM convolution core for gfx950 (MI355X, CDNA4).
+//
+// One kernel template serves every dense contraction on the gaze path: the
+// 1024->P projection, the hoisted ConvGRU input convolutions, the per-step
+// recurrent convolutions (gate math fused in the epilogue), the transposed
+// convolutions of the saliency head (as gather-form sub-pixel phases) and the
+// C3D 3x3x3 convolutions (bias + ReLU + max-pool fused in the epilogue).
+//
+//   Out[m, n] = sum_k A[m, k] * Wp[n, k]
+//
+// * A is never materialised.  Activations live in HBM as halo-padded
+//   channels-last images, so row m's operand is   A + rowin[m] + koff[kt]
+//   with no bounds checks: rowin comes from a per-image offset table (any row
+//   order -- pooling-window-major for the fused max-pool, phase-major for the
+//   transposed convs), koff from a per-K-chunk table of tap offsets.
+// * Wp is the filter pre-packed as [N][K] (K contiguous), so both MFMA operands
+//   are 16-byte K-contiguous fragments.
+// * Both tiles are staged by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//   instruction = 8 rows x 128 B) into a double buffer.  LDS images are
+//   lane-linear, so the bank-conflict XOR swizzle (16-B chunk ^= row&7) is
+//   applied on the per-lane SOURCE address and again on the ds_read_b128.
+// * T = bf16 : v_mfma_f32_16x16x32_bf16, 64 elements per 128-B K-chunk.
+//   T = f32  : v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), 32 per chunk.
+//   Accumulation is always fp32.
+// * The epilogue round-trips the accumulators through LDS one wave-row slab at
+//   a time so that every thread owns 8 consecutive output channels of one output
+//   row (16-B coalesced stores) and can reduce the P rows of a pooling window.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rgp {
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int BKE = 32;  // elements per 128-byte K-chunk
+  static constexpr int EPC = 4;   // elements per 16-byte LDS chunk
+  static __device__ __forceinline__ float to(float v) { return v; }
+  static __device__ __forceinline__ float from(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int BKE = 64;
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ bf16_t to(float v) { return f2bf(v); }
+  static __device__ __forceinline__ float from(bf16_t v) { return bf2f(v); }
+};
+
+struct IgemmParams {
+  const void* A;             // activation base (T)
+  const void* W;             // packed filter [Npad][K] (T), Npad multiple of 128
+  const int* in_tab;         // [Mw] element offset of row's receptive-field origin inside one image
+  const int* koff;           // [nk*G] element offset added for each K-(sub)chunk
+  long long in_img_stride;   // elements between images
+  int Mw;                    // rows per image
+  int M;                     // total rows
+  int N;                     // real output channels
+  int K;                     // packed K (multiple of BKE)
+  int nk;                    // K / BKE
+};
+
+// Epilogue operands (superset; each functor reads what it needs).
+struct EpiParams {
+  void* out;                 // primary output
+  const int* out_tab;        // [Mw/P] element offset of an output row inside one output image
+  long long out_img_stride;  // elements
+  const float* bias;         // [N]
+  // ConvGRU gate epilogues (gaze_grcn.py:118-127)
+  const float* xpre;         // hoisted W*x pre-activations for this step, [img][49][xpre_ld]
+  long long xpre_img_stride;
+  int xpre_ld;
+  int xpre_col;              // column of this kernel's first gate inside xpre
+  int S;                     // state channels
+  int state_rows;            // rows per state image (49)
+  const float* h_prev;       // [img][Mw][S] fp32 state h_{t-1}
+  float* h_next;             // [img][Mw][S] fp32 state h_t
+  float* u_gate;             // [img][Mw][S] update gate (written by ZR, read by C)
+  float* r_save;             // optional [img][Mw][S]
+  float* c_save;             // optional [img][Mw][S]
+  void* out2;                // C epilogue: batch-normalised h_t for the head
+  const int* out2_tab;
+  long long out2_img_stride;
+  long long out2_img_mul;    // head image index = img*out2_img_mul + out2_img_add  (b*T + t)
+  long long out2_img_add;
+  const float* bn_gamma;     // [S] of this timestep
+  const float* bn_beta;
+  float bn_inv_std;
+};
+
+// ---------------------------------------------------------------------------
+// Epilogue functors.  apply() gets 8 consecutive output channels n0..n0+7 of one
+// (pooled) output row; img/ml identify the row (ml = row index inside the image,
+// already divided by the pooling factor).
+// ---------------------------------------------------------------------------
+template <typename TO> __device__ __forceinline__ void store8(TO* dst, const float* v, int nvalid);
+template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v, int nvalid) {
+  if (nvalid >= 8) {
+    *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  } else {
+    for (int i = 0; i < nvalid; ++i) dst[i] = v[i];
+  }
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v, int nvalid) {
+  if (nvalid >= 8) {
+    u32x4 pk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    *(u32x4*)dst = pk;
+  } else {
+    for (int i = 0; i < nvalid; ++i) dst[i] = f2bf(v[i]);
+  }
+}
+
+// out = [relu](acc + bias) stored as TO.
+template <typename TO, bool BIAS, bool RELU> struct EpiStore {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    const int nvalid = N - n0;
+    if (nvalid <= 0) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (BIAS) v[i] += (i < nvalid) ? e.bias[n0 + i] : 0.f;
+      if (RELU) v[i] = fmaxf(v[i], 0.f);
+    }
+    TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_tab[ml] + n0;
+    store8<TO>(dst, v, nvalid);
+  }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  const float e = expf(-2.f * fabsf(x));
+  const float t = (1.f - e) / (1.f + e);
+  return copysignf(t, x);
+}
+
+// Update / reset gates:  u = sigmoid(Wz*x + Uz*h), r = sigmoid(Wr*x + Ur*h)
+// (gaze_grcn.py:108-119).  Columns [0,S) are z, [S,2S) are r.  Writes u (fp32)
+// and the candidate conv's operand r*h (T, halo-padded state image).
+template <typename T> struct EpiGruZR {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    if (n0 >= N) return;
+    const float* xp = e.xpre + (long long)img * e.xpre_img_stride + (long long)ml * e.xpre_ld + e.xpre_col + n0;
+    const f32x4 x0 = *(const f32x4*)xp, x1 = *(const f32x4*)(xp + 4);
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = sigmoidf_(v[i] + (i < 4 ? x0[i] : x1[i - 4]));
+    const long long srow = ((long long)img * e.state_rows + ml) * e.S;
+    if (n0 < e.S) {
+      store8<float>(e.u_gate + srow + n0, g, 8);
+    } else {
+      const int c0 = n0 - e.S;
+      const f32x4 h0 = *(const f32x4*)(e.h_prev + srow + c0), h1 = *(const f32x4*)(e.h_prev + srow + c0 + 4);
+      if (e.r_save) store8<float>(e.r_save + srow + c0, g, 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] *= (i < 4 ? h0[i] : h1[i - 4]);
+      store8<T>((T*)e.out + (long long)img * e.out_img_stride + e.out_tab[ml] + c0, g, 8);
+    }
+  }
+};
+
+// Candidate + blend:  c = tanh(W*x + U*(r.h)),  h' = u*h + (1-u)*c
+// (gaze_grcn.py:122-127), then the per-timestep inference batch-norm
+// (gaze_grcn.py:325) for the head.  Writes h' (fp32 state), h' (T, padded, next
+// step's operand) and BN(h') (T, padded head image of frame img*mul+add = b*T+t).
+template <typename T> struct EpiGruC {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    if (n0 >= N) return;
+    const float* xp = e.xpre + (long long)img * e.xpre_img_stride + (long long)ml * e.xpre_ld + e.xpre_col + n0;
+    const f32x4 x0 = *(const f32x4*)xp, x1 = *(const f32x4*)(xp + 4);
+    const long long srow = ((long long)img * e.state_rows + ml) * e.S + n0;
+    const f32x4 u0 = *(const f32x4*)(e.u_gate + srow), u1 = *(const f32x4*)(e.u_gate + srow + 4);
+    const f32x4 h0 = *(const f32x4*)(e.h_prev + srow), h1 = *(const f32x4*)(e.h_prev + srow + 4);
+    float c[8], hn[8], hb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float u = i < 4 ? u0[i] : u1[i - 4];
+      const float h = i < 4 ? h0[i] : h1[i - 4];
+      c[i] = tanhf_(v[i] + (i < 4 ? x0[i] : x1[i - 4]));
+      hn[i] = u * h + (1.f - u) * c[i];
+      hb[i] = e.bn_gamma[n0 + i] * (hn[i] * e.bn_inv_std) + e.bn_beta[n0 + i];
+    }
+    if (e.c_save) store8<float>(e.c_save + srow, c, 8);
+    store8<float>(e.h_next + srow, hn, 8);
+    store8<T>((T*)e.out + (long long)img * e.out_img_stride + e.out_tab[ml] + n0, hn, 8);
+    const long long himg = (long long)img * e.out2_img_mul + e.out2_img_add;
+    store8<T>((T*)e.out2 + himg * e.out2_img_stride + e.out2_tab[ml] + n0, hb, 8);
+  }
+};
+
+// ---------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void step(f32x4& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void step(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+  }
+};
+
+template <int BM, int BN> struct IgemmSmem {
+  static constexpr int TILE_BYTES = (BM + BN) * 128;
+  static constexpr int ROWINFO_OFF = 2 * TILE_BYTES;
+  static constexpr int BYTES = ROWINFO_OFF + BM * 16;   // int64 rowin + int img + int ml per row
+};
+
+// G = K-subchunks per 128-byte chunk that carry their own tap offset (1 for
+// Cin*sizeof(T) >= 128 B; 2/4 when a 128-B chunk spans several taps).
+// P = rows per pooling window (1, 4 or 8), rows of a window are consecutive in m.
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p, const EpiParams e) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8 + NW - 1) / NW;
+  constexpr int BKE = Elem<T>::BKE;
+  constexpr int ESZ = sizeof(T);
+  constexpr int TILE_BYTES = IgemmSmem<BM, BN>::TILE_BYTES;
+  static_assert((BM / 8) % NW == 0, "A groups must divide over waves");
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile");
+  static_assert(WTM % P == 0, "pool window inside a slab");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  long long* s_rowin = (long long*)(smem + IgemmSmem<BM, BN>::ROWINFO_OFF);
+  int* s_rowimg = (int*)(s_rowin + BM);
+  int* s_rowml = s_rowimg + BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each
+  // XCD a contiguous run of tiles so halo rows / weight panels are L2 hits.
+  const int n_nt = (p.N + BN - 1) / BN;
+  const int n_mt = (p.M + BM - 1) / BM;
+  const int nwg = n_mt * n_nt;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, y = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int mt = bid / n_nt, nt = bid % n_nt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  for (int r = tid; r < BM; r += NT) {
+    int m = m0 + r;
+    const bool valid = m < p.M;
+    if (!valid) m = p.M - 1;
+    const int img = m / p.Mw, ml = m - img * p.Mw;
+    s_rowin[r] = (long long)img * p.in_img_stride + p.in_tab[ml];
+    s_rowimg[r] = valid ? img : -1;
+    s_rowml[r] = ml;
+  }
+  __syncthreads();
+
+  // Per-lane source bases.  A wave instruction fills 8 rows x 128 B: lane l ->
+  // row l>>3, physical 16-B slot l&7, which holds logical chunk (l&7)^(l>>3).
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const char* a_src[A_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int r = (wave * A_PER_WAVE + j) * 8 + lrow;
+    a_src[j] = (const char*)p.A + s_rowin[r] * ESZ + (lchunk % (8 / G)) * 16;
+  }
+  const int asub = lchunk / (8 / G);
+  const char* b_src[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    const int r = (wave * B_PER_WAVE + j) * 8 + lrow;
+    b_src[j] = (const char*)p.W + ((long long)(n0 + r) * p.K) * ESZ + lchunk * 16;
+  }
+  const bool b_active = (BN / 8 >= NW) || (wave < BN / 8);
+
+  auto stage = [&](int buf, int kt) {
+    char* abuf = smem + buf * TILE_BYTES;
+    char* bbuf = abuf + BM * 128;
+    long long ko;
+    if (G == 1) ko = (long long)p.koff[kt] * ESZ;
+    else ko = (long long)p.koff[kt * G + asub] * ESZ;
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + ko),
+                                       (__attribute__((address_space(3))) void*)(abuf + (wave * A_PER_WAVE + j) * 1024),
+                                       16, 0, 0);
+    }
+    if (b_active) {
+      const long long kb = (long long)kt * 128;
+#pragma unroll
+      for (int j = 0; j < B_PER_WAVE; ++j) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + kb),
+                                         (__attribute__((address_space(3))) void*)(bbuf + (wave * B_PER_WAVE + j) * 1024),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* abuf = smem + buf * TILE_BYTES + (wm * WTM + frow) * 128;
+    const char* bbuf = smem + buf * TILE_BYTES + BM * 128 + (wn * WTN + frow) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int pc = ((s * 4 + fk) ^ (frow & 7)) * 16;
+      f32x4 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *(const f32x4*)(abuf + i * 16 * 128 + pc);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *(const f32x4*)(bbuf + j * 16 * 128 + pc);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < p.nk - 1; ++kt) {
+    stage(cur ^ 1, kt + 1);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  compute(cur);
+  __syncthreads();
+
+  // ---- epilogue: one wave-row slab (WTM rows x BN cols, fp32) at a time ----
+  constexpr int LDS_LD = BN + 4;
+  float* stg = (float*)smem;
+  static_assert(WTM * LDS_LD * 4 <= 2 * TILE_BYTES, "staging fits in the tile buffers");
+  constexpr int CG = BN / 8;
+  constexpr int ITEMS = (WTM / P) * CG;
+#pragma unroll 1
+  for (int slab = 0; slab < WM; ++slab) {
+    if (wm == slab) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stg[(i * 16 + fk * 4 + r) * LDS_LD + wn * WTN + j * 16 + frow] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int it = tid; it < ITEMS; it += NT) {
+      const int g = it / CG, cg = it - g * CG;
+      const int rt = slab * WTM + g * P;
+      const int img = s_rowimg[rt];
+      if (img >= 0) {
+        float v[8];
+        const float* src = stg + (g * P) * LDS_LD + cg * 8;
+        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+#pragma unroll
+        for (int q = 1; q < P; ++q) {
+          const f32x4 w0 = *(const f32x4*)(src + q * LDS_LD), w1 = *(const f32x4*)(src + q * LDS_LD + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], w0[i]); v1[i] = fmaxf(v1[i], w1[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+        Epi::apply(e, p.N, img, s_rowml[rt] / P, n0 + cg * 8, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace rgp

@@ -1,0 +1,167 @@
+// Layout / packing / softmax kernels around the implicit-GEMM core (gfx950).
+// All are HBM-bound streaming kernels: 16-byte vector accesses, 256-thread
+// blocks, no cross-block communication.
+#pragma once
+#include "igemm.hip.h"
+
+namespace rgp {
+
+// c3d_input [F][C][49] f32 (the reference's placeholder layout, gaze_rnn.py:118-121)
+// -> rows [F*49][C] of T: the transpose of gaze_grcn.py:225-227 fused with the
+// operand conversion.  One block = one frame x 64 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int C) {
+  __shared__ float tile[64][50];
+  const int f = blockIdx.y, c0 = blockIdx.x * 64;
+  const float* src = x + ((long long)f * C + c0) * 49;
+  for (int i = threadIdx.x; i < 64 * 49; i += 256) tile[i / 49][i % 49] = src[i];
+  __syncthreads();
+  for (int it = threadIdx.x; it < 49 * 8; it += 256) {
+    const int p = it >> 3, cg = it & 7;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = tile[cg * 8 + i][p];
+    store8<T>(y + ((long long)f * 49 + p) * C + c0 + cg * 8, v, 8);
+  }
+}
+
+// Generic filter packer: dst[(row0+n)*K + tap*cin_k + c] =
+//   src[tap_src[tap]*s_tap + n*s_n + c*s_c]   (0 if tap_src<0 or c>=cin_src).
+// Covers HWIO/DHWIO conv filters, the [kh,kw,out,in] transposed-conv filters per
+// sub-pixel phase, 180-degree rotated filters for dgrad, and channel padding.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                          const int* __restrict__ tap_src, int ntaps, int cin_k,
+                                                          int cin_src, int n_rows, int row0, int K, long long s_tap,
+                                                          long long s_n, long long s_c) {
+  const long long total = (long long)n_rows * ntaps * cin_k;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cin_k);
+    const int tap = (int)((i / cin_k) % ntaps);
+    const int n = (int)(i / ((long long)cin_k * ntaps));
+    const int ts = tap_src ? tap_src[tap] : tap;
+    float v = 0.f;
+    if (ts >= 0 && c < cin_src) v = src[ts * s_tap + n * s_n + c * s_c];
+    dst[(long long)(row0 + n) * K + tap * cin_k + c] = Elem<T>::to(v);
+  }
+}
+
+// Exact algebraic fold of the 7x7 transposed conv (12 channels) with the 12->1
+// projection (gaze_grcn.py:353-361): G[tap][c] = sum_o F[tap][o][c] * out_W[o].
+static __global__ void fold_head_filter_kernel(const float* __restrict__ f, const float* __restrict__ out_w,
+                                        float* __restrict__ g, int ntaps, int co, int ci) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntaps * ci) return;
+  const int tap = i / ci, c = i % ci;
+  float s = 0.f;
+  for (int o = 0; o < co; ++o) s += f[((long long)tap * co + o) * ci + c] * out_w[o];
+  g[i] = s;
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float w = __shfl_xor(v, o);
+    v = is_max ? fmaxf(v, w) : v + w;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+// Per-frame softmax over the n (=2401) pixels (model_util.py:61-64) and, when
+// labels are given, the per-frame cross entropy -sum g*log_softmax(z)
+// (model_util.py:66-72).  One block per frame; the row lives in registers.
+static __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ z, const float* __restrict__ labels,
+                                                           float* __restrict__ probs, float* __restrict__ frame_loss,
+                                                           int n) {
+  __shared__ float sh[4];
+  const long long row = blockIdx.x;
+  const float* zr = z + row * n;
+  float v[12];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int j = threadIdx.x + i * 256;
+    v[i] = j < n ? zr[j] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = block_reduce(mx, sh, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int j = threadIdx.x + i * 256;
+    v[i] = j < n ? expf(v[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  sum = block_reduce(sum, sh, false);
+  const float inv = 1.f / sum;
+  if (probs) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < n) probs[row * n + j] = v[i] * inv;
+    }
+  }
+  if (labels && frame_loss) {
+    const float lse = mx + logf(sum);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int j = threadIdx.x + i * 256;
+      if (j < n) acc += labels[row * n + j] * (lse - zr[j]);
+    }
+    acc = block_reduce(acc, sh, false);
+    if (threadIdx.x == 0) frame_loss[row] = acc;
+  }
+}
+
+// Deterministic sum of the per-frame losses divided by B*T (gaze_rnn.py:406-407).
+static __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ frame_loss, float* __restrict__ loss,
+                                                          int n, float scale) {
+  __shared__ float sh[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += frame_loss[i];
+  a = block_reduce(a, sh, false);
+  if (threadIdx.x == 0) *loss = a * scale;
+}
+
+// video [N][D][H][W][3] f32 (mean-subtracted) -> halo-padded channels-last
+// [N][D+2][H+2][W+4][4] of T (x halo: 1 left, 3 right; 4th channel 0) so conv1a's
+// (kx, c) taps are one contiguous 32-byte run per (kz, ky) and need no bounds test.
+template <typename T>
+__global__ __launch_bounds__(256) void video_prep_kernel(const float* __restrict__ v, T* __restrict__ out, long long npix,
+                                                         int D, int H, int W) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int z = (int)((i / ((long long)W * H)) % D);
+    const long long n = i / ((long long)W * H * D);
+    const float* s = v + i * 3;
+    const long long o = (((n * (D + 2) + z + 1) * (H + 2) + y + 1) * (long long)(W + 4) + x + 1) * 4;
+    out[o + 0] = Elem<T>::to(s[0]);
+    out[o + 1] = Elem<T>::to(s[1]);
+    out[o + 2] = Elem<T>::to(s[2]);
+    out[o + 3] = Elem<T>::to(0.f);
+  }
+}
+
+// conv5b rows [F*49][d*512+c] (T) -> the reference's feature layout
+// [F][1024 = c*2+d][7][7] f32 (gaze_rnn.py:494-497).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_c3d_features_kernel(const T* __restrict__ rows, float* __restrict__ feat,
+                                                                   long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int p = (int)(i % 49);
+    const int ch = (int)((i / 49) % 1024);
+    const long long f = i / (49 * 1024);
+    const int c = ch >> 1, d = ch & 1;
+    feat[i] = Elem<T>::from(rows[(f * 49 + p) * 1024 + d * 512 + c]);
+  }
+}
+
+}  // namespace rgp

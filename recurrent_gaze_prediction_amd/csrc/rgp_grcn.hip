@@ -1,0 +1,465 @@
+// librgp_hip.so: the gaze_grcn head (projection, ConvGRU, transposed-conv saliency
+// head) -- plan object, workspace layout and stage launches.
+// Reference graph: /root/reference/models/gaze_grcn.py:173-376.
+#include <algorithm>
+#include <map>
+
+#include "rgp_host.h"
+
+using namespace rgp;
+
+struct Buf {
+  size_t off = 0, bytes = 0;
+};
+
+struct rgp_grcn {
+  int B = 0, T = 0, P = 0, S = 0, dtype = RGP_BF16, save = 0, F = 0;
+  ConvDesc proj, proj_rows, xconv, gzr, gc, d3;
+  std::vector<ConvDesc> d1, d2;
+  // read_buffer tables (host copies + offsets)
+  std::vector<int> tab_pad9_P, tab_pad9_S, tab_pad27, tab_pad55, tab_lin49_3S, tab_lin49_S;
+  size_t o_pad9_P = 0, o_pad9_S = 0, o_pad27 = 0, o_pad55 = 0, o_lin49_3S = 0, o_lin49_S = 0;
+  Buf xt, E, xpre, hall, uall, rall, call, hp, rhp, hbn, D1, D2, gfold, frame_loss;
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  bool weights_set = false;
+  const float *bn_gamma = nullptr, *bn_beta = nullptr, *proj_b = nullptr, *out_b = nullptr;
+};
+
+namespace {
+
+Buf take(Arena& a, size_t bytes) {
+  Buf b;
+  b.bytes = bytes;
+  b.off = a.take(bytes);
+  return b;
+}
+
+// Gather-form sub-pixel phases of tf.nn.conv2d_transpose(VALID, stride s, k x k,
+// filter [k,k,Cout,Cin]) (gaze_grcn.py:326-343):
+//   out[s*i+py, s*j+px, o] = sum_{a',b',c} in[i-a', j-b', c] * F[py+s*a', px+s*b', o, c]
+// Input image is halo-padded by hin (>= taps-1), output image by hout.
+bool build_deconv_phases(std::vector<ConvDesc>& out, int k, int s, int H, int hin, int Cin, int OH, int hout, int Cout,
+                         int dtype) {
+  const int Wp = H + 2 * hin, OWp = OH + 2 * hout;
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px) {
+      const int ta = (k - py + s - 1) / s, tb = (k - px + s - 1) / s;
+      const int Hph = (OH - py + s - 1) / s, Wph = (OH - px + s - 1) / s;
+      if (hin < ta - 1 || hin < tb - 1 || Hph > H + hin || Wph > H + hin) return false;
+      ConvDesc d;
+      d.Mw = Hph * Wph;
+      d.N = Cout;
+      d.in_img_stride = (long long)Wp * Wp * Cin;
+      d.out_img_stride = (long long)OWp * OWp * Cout;
+      for (int i = 0; i < Hph; ++i)
+        for (int j = 0; j < Wph; ++j) {
+          d.in_tab.push_back(((i - (ta - 1) + hin) * Wp + (j - (tb - 1) + hin)) * Cin);
+          d.out_tab.push_back(((s * i + py + hout) * OWp + (s * j + px + hout)) * Cout);
+        }
+      std::vector<int> tapoff, fidx;
+      for (int u = 0; u < ta; ++u)
+        for (int v = 0; v < tb; ++v) {
+          tapoff.push_back((u * Wp + v) * Cin);
+          fidx.push_back((py + s * (ta - 1 - u)) * k + (px + s * (tb - 1 - v)));
+        }
+      if (!build_k_schedule(d, tapoff, fidx, Cin, dtype)) return false;
+      d.s_tap = (long long)Cout * Cin;
+      d.s_n = Cin;
+      d.s_c = 1;
+      out.push_back(d);
+    }
+  return true;
+}
+
+std::vector<int> pad_tab(int H, int halo, int C) {
+  std::vector<int> t;
+  const int Wp = H + 2 * halo;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < H; ++x) t.push_back(((y + halo) * Wp + x + halo) * C);
+  return t;
+}
+
+size_t put_tab(Arena& a, const std::vector<int>& t) { return a.take(t.size() * 4); }
+
+template <typename T, int G>
+int run_d3(rgp_grcn* g, float* logits, hipStream_t s) {
+  IgemmParams p = make_params(g->d3, g->ws + g->D2.off, g->ws, g->F);
+  EpiParams e = make_epi(g->d3, logits, g->ws);
+  e.bias = g->out_b;
+  return launch_igemm<T, G, 1, EpiStore<float, true, false>>(p, e, s);
+}
+
+template <typename T>
+int proj_impl(rgp_grcn* g, const float* c3d_input, const void* rows, hipStream_t s) {
+  const ConvDesc& d = rows ? g->proj_rows : g->proj;
+  const void* A = rows;
+  if (!rows) {
+    nchw_to_rows_kernel<T><<<dim3(1024 / 64, g->F), 256, 0, s>>>(c3d_input, (T*)(g->ws + g->xt.off), 1024);
+    RGP_HIP(hipGetLastError());
+    A = g->ws + g->xt.off;
+  }
+  IgemmParams p = make_params(d, A, g->ws, g->F);
+  EpiParams e = make_epi(d, g->ws + g->E.off, g->ws);
+  e.bias = g->proj_b;
+  return launch_igemm<T, 1, 1, EpiStore<T, true, false>>(p, e, s);
+}
+
+template <typename T>
+int xconv_impl(rgp_grcn* g, hipStream_t s) {
+  IgemmParams p = make_params(g->xconv, g->ws + g->E.off, g->ws, g->F);
+  EpiParams e = make_epi(g->xconv, g->ws + g->xpre.off, g->ws);
+  return launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s);
+}
+
+template <typename T>
+int seq_impl(rgp_grcn* g, hipStream_t s) {
+  const int B = g->B, T_ = g->T, S = g->S;
+  const size_t st = (size_t)B * 49 * S;  // fp32 elements per state snapshot
+  RGP_HIP(hipMemsetAsync(g->ws + g->hp.off, 0, g->hp.bytes, s));      // h_0 = 0 (gaze_grcn.py:262)
+  RGP_HIP(hipMemsetAsync(g->ws + g->hall.off, 0, st * 4, s));
+  float* hall = (float*)(g->ws + g->hall.off);
+  float* uall = (float*)(g->ws + g->uall.off);
+  float* rall = g->save ? (float*)(g->ws + g->rall.off) : nullptr;
+  float* call = g->save ? (float*)(g->ws + g->call.off) : nullptr;
+  for (int t = 0; t < T_; ++t) {
+    EpiParams e = make_epi(g->gzr, g->ws + g->rhp.off, g->ws);
+    e.xpre = (const float*)(g->ws + g->xpre.off) + (size_t)t * 49 * 3 * S;
+    e.xpre_img_stride = (long long)T_ * 49 * 3 * S;
+    e.xpre_ld = 3 * S;
+    e.xpre_col = 0;
+    e.S = S;
+    e.state_rows = 49;
+    e.h_prev = hall + (size_t)t * st;
+    e.h_next = hall + (size_t)(t + 1) * st;
+    e.u_gate = uall + (size_t)t * st;
+    e.r_save = rall ? rall + (size_t)t * st : nullptr;
+    e.c_save = call ? call + (size_t)t * st : nullptr;
+    IgemmParams p = make_params(g->gzr, g->ws + g->hp.off, g->ws, B);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiGruZR<T>>(p, e, s)));
+    // candidate conv on r*h, blend, BN -> next operand + head image b*T+t
+    e.out = g->ws + g->hp.off;
+    e.out_tab = (const int*)(g->ws + g->gc.out_tab_off);
+    e.out_img_stride = g->gc.out_img_stride;
+    e.xpre_col = 2 * S;
+    e.out2 = g->ws + g->hbn.off;
+    e.out2_tab = (const int*)(g->ws + g->gc.out_tab_off);
+    e.out2_img_stride = 81LL * S;
+    e.out2_img_mul = T_;
+    e.out2_img_add = t;
+    e.bn_gamma = g->bn_gamma + (size_t)t * S;
+    e.bn_beta = g->bn_beta + (size_t)t * S;
+    e.bn_inv_std = 1.0f / sqrtf(1.0f + 1e-3f);  // moving mean 0 / var 1, eps 1e-3
+    IgemmParams pc = make_params(g->gc, g->ws + g->rhp.off, g->ws, B);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiGruC<T>>(pc, e, s)));
+  }
+  return RGP_OK;
+}
+
+template <typename T>
+int head_impl(rgp_grcn* g, float* logits, hipStream_t s) {
+  for (const ConvDesc& d : g->d1) {
+    IgemmParams p = make_params(d, g->ws + g->hbn.off, g->ws, g->F);
+    EpiParams e = make_epi(d, g->ws + g->D1.off, g->ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+  }
+  for (const ConvDesc& d : g->d2) {
+    IgemmParams p = make_params(d, g->ws + g->D1.off, g->ws, g->F);
+    EpiParams e = make_epi(d, g->ws + g->D2.off, g->ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+  }
+  if (sizeof(T) == 2) return run_d3<T, 2>(g, logits, s);
+  return run_d3<T, 1>(g, logits, s);
+}
+
+template <typename T>
+int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
+  char* ws = g->ws;
+  const int S = g->S, P = g->P;
+  RGP_HIP(hipMemsetAsync(ws + g->proj.w_off, 0, g->proj.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->proj, w->proj_c3d_W, ws, P, 0, s));
+  RGP_HIP(hipMemsetAsync(ws + g->proj_rows.w_off, 0, g->proj_rows.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->proj_rows, w->proj_c3d_W, ws, P, 0, s));
+  RGP_HIP(hipMemsetAsync(ws + g->xconv.w_off, 0, g->xconv.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->xconv, w->gru_Wz, ws, S, 0, s));
+  RGP_TRY(pack_filter<T>(g->xconv, w->gru_Wr, ws, S, S, s));
+  RGP_TRY(pack_filter<T>(g->xconv, w->gru_W, ws, S, 2 * S, s));
+  RGP_HIP(hipMemsetAsync(ws + g->gzr.w_off, 0, g->gzr.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->gzr, w->gru_Uz, ws, S, 0, s));
+  RGP_TRY(pack_filter<T>(g->gzr, w->gru_Ur, ws, S, S, s));
+  RGP_HIP(hipMemsetAsync(ws + g->gc.w_off, 0, g->gc.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->gc, w->gru_U, ws, S, 0, s));
+  for (ConvDesc& d : g->d1) {
+    RGP_HIP(hipMemsetAsync(ws + d.w_off, 0, d.w_bytes(g->dtype), s));
+    RGP_TRY(pack_filter<T>(d, w->up_weight1, ws, 64, 0, s));
+  }
+  for (ConvDesc& d : g->d2) {
+    RGP_HIP(hipMemsetAsync(ws + d.w_off, 0, d.w_bytes(g->dtype), s));
+    RGP_TRY(pack_filter<T>(d, w->up_weight2, ws, 32, 0, s));
+  }
+  float* gf = (float*)(ws + g->gfold.off);
+  fold_head_filter_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(w->up_weight3, w->out_W, gf, 49, 12, 32);
+  RGP_HIP(hipGetLastError());
+  RGP_HIP(hipMemsetAsync(ws + g->d3.w_off, 0, g->d3.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->d3, gf, ws, 1, 0, s));
+  g->bn_gamma = w->bn_gamma;
+  g->bn_beta = w->bn_beta;
+  g->proj_b = w->proj_c3d_b;
+  g->out_b = w->out_b;
+  g->weights_set = true;
+  return RGP_OK;
+}
+
+int check_ready(const rgp_grcn* g) {
+  if (!g) return set_err(RGP_EINVAL, "null plan");
+  if (!g->ws) return set_err(RGP_EWORKSPACE, "rgp_grcn: workspace not bound");
+  if (!g->weights_set) return set_err(RGP_ESTATE, "rgp_grcn: weights not set");
+  return RGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int dim_state, int dtype,
+                    int save_for_backward) {
+  RGP_REQUIRE(plan, "rgp_grcn_create: null out pointer");
+  RGP_REQUIRE(batch > 0 && n_steps > 0, "rgp_grcn_create: batch=%d n_steps=%d", batch, n_steps);
+  RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_grcn_create: dtype %d", dtype);
+  const int Bk = bke(dtype);
+  RGP_REQUIRE(dim_proj > 0 && dim_proj % 64 == 0 && dim_state > 0 && dim_state % 64 == 0,
+              "rgp_grcn_create: dim_proj=%d dim_state=%d must be multiples of 64", dim_proj, dim_state);
+  RGP_REQUIRE((long long)batch * n_steps * 2401 < (1LL << 31), "rgp_grcn_create: B*T too large");
+  (void)Bk;
+  rgp_grcn* g = new rgp_grcn();
+  g->B = batch; g->T = n_steps; g->P = dim_proj; g->S = dim_state; g->dtype = dtype; g->save = save_for_backward;
+  g->F = batch * n_steps;
+  const int P = g->P, S = g->S, F = g->F, es = esize(dtype);
+  bool ok = true;
+
+  // projection  E = X W + b  (gaze_grcn.py:239-242), output halo-padded 9x9xP
+  for (ConvDesc* d : {&g->proj, &g->proj_rows}) {
+    d->Mw = 49; d->N = P;
+    d->in_img_stride = 49LL * 1024; d->out_img_stride = 81LL * P;
+    for (int p = 0; p < 49; ++p) d->in_tab.push_back(p * 1024);
+    d->out_tab = pad_tab(7, 1, P);
+  }
+  ok &= build_k_schedule(g->proj, {0}, {0}, 1024, dtype);
+  g->proj.s_tap = 0; g->proj.s_n = 1; g->proj.s_c = P;
+  // rows from C3D carry K order d*512+c; reference channel = c*2+d
+  ok &= build_k_schedule(g->proj_rows, {0, 512}, {0, 1}, 512, dtype);
+  g->proj_rows.s_tap = P; g->proj_rows.s_n = 1; g->proj_rows.s_c = 2LL * P;
+
+  // 3x3 SAME convs on the padded 7x7 maps
+  auto conv3x3 = [&](ConvDesc& d, int Cin, int N) {
+    d.Mw = 49; d.N = N; d.in_img_stride = 81LL * Cin;
+    for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x) d.in_tab.push_back((y * 9 + x) * Cin);
+    std::vector<int> tapoff, fidx;
+    for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) { tapoff.push_back((ky * 9 + kx) * Cin); fidx.push_back(ky * 3 + kx); }
+    bool r = build_k_schedule(d, tapoff, fidx, Cin, dtype);
+    d.s_tap = (long long)Cin * S;  // HWIO filters [3,3,Cin,S]: src[(tap*Cin + c)*S + n]
+    d.s_n = 1; d.s_c = S;
+    return r;
+  };
+  ok &= conv3x3(g->xconv, P, 3 * S);
+  for (int p = 0; p < 49; ++p) g->xconv.out_tab.push_back(p * 3 * S);
+  g->xconv.out_img_stride = 49LL * 3 * S;
+  ok &= conv3x3(g->gzr, S, 2 * S);
+  g->gzr.out_tab = pad_tab(7, 1, S); g->gzr.out_img_stride = 81LL * S;
+  ok &= conv3x3(g->gc, S, S);
+  g->gc.out_tab = pad_tab(7, 1, S); g->gc.out_img_stride = 81LL * S;
+
+  ok &= build_deconv_phases(g->d1, 5, 3, 7, 1, S, 23, 2, 64, dtype);    // gaze_grcn.py:326-333
+  ok &= build_deconv_phases(g->d2, 5, 2, 23, 2, 64, 49, 3, 32, dtype);  // gaze_grcn.py:336-343
+
+  // 7x7 SAME stride-1 transposed conv folded with the 12->1 projection
+  // (gaze_grcn.py:353-361): logit[y,x] = sum in[y-a+3, x-b+3, c] G[a,b,c] + out_b.
+  {
+    ConvDesc& d = g->d3;
+    d.Mw = 2401; d.N = 1; d.in_img_stride = 55LL * 55 * 32; d.out_img_stride = 2401;
+    for (int y = 0; y < 49; ++y) for (int x = 0; x < 49; ++x) { d.in_tab.push_back((y * 55 + x) * 32); d.out_tab.push_back(y * 49 + x); }
+    std::vector<int> tapoff, fidx;
+    for (int u = 0; u < 7; ++u) for (int v = 0; v < 7; ++v) { tapoff.push_back((u * 55 + v) * 32); fidx.push_back((6 - u) * 7 + (6 - v)); }
+    ok &= build_k_schedule(d, tapoff, fidx, 32, dtype);
+    d.s_tap = 32; d.s_n = 0; d.s_c = 1;
+  }
+  if (!ok) { delete g; return set_err(RGP_EINVAL, "rgp_grcn_create: unsupported channel geometry P=%d S=%d", P, S); }
+
+  Arena a;
+  for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3}) d->reserve(a, dtype);
+  for (ConvDesc& d : g->d1) d.reserve(a, dtype);
+  for (ConvDesc& d : g->d2) d.reserve(a, dtype);
+  g->tab_pad9_P = pad_tab(7, 1, P); g->o_pad9_P = put_tab(a, g->tab_pad9_P);
+  g->tab_pad9_S = pad_tab(7, 1, S); g->o_pad9_S = put_tab(a, g->tab_pad9_S);
+  g->tab_pad27 = pad_tab(23, 2, 64); g->o_pad27 = put_tab(a, g->tab_pad27);
+  g->tab_pad55 = pad_tab(49, 3, 32); g->o_pad55 = put_tab(a, g->tab_pad55);
+  for (int p = 0; p < 49; ++p) { g->tab_lin49_3S.push_back(p * 3 * S); g->tab_lin49_S.push_back(p * S); }
+  g->o_lin49_3S = put_tab(a, g->tab_lin49_3S); g->o_lin49_S = put_tab(a, g->tab_lin49_S);
+
+  const size_t st = (size_t)batch * 49 * S * 4;
+  g->xt = take(a, (size_t)F * 49 * 1024 * es);
+  g->E = take(a, (size_t)F * 81 * P * es);
+  g->xpre = take(a, (size_t)F * 49 * 3 * S * 4);
+  g->hall = take(a, st * (n_steps + 1));
+  g->uall = take(a, st * n_steps);
+  if (g->save) { g->rall = take(a, st * n_steps); g->call = take(a, st * n_steps); }
+  g->hp = take(a, (size_t)batch * 81 * S * es);
+  g->rhp = take(a, (size_t)batch * 81 * S * es);
+  g->hbn = take(a, (size_t)F * 81 * S * es);
+  g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
+  g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es);
+  g->gfold = take(a, 50 * 32 * 4);
+  g->frame_loss = take(a, (size_t)F * 4);
+  g->ws_bytes = a.off;
+  *plan = g;
+  return RGP_OK;
+}
+
+int rgp_grcn_destroy(rgp_grcn_t* plan) {
+  delete plan;
+  return RGP_OK;
+}
+
+size_t rgp_grcn_workspace_bytes(const rgp_grcn_t* plan) { return plan ? plan->ws_bytes : 0; }
+
+int rgp_grcn_bind_workspace(rgp_grcn_t* g, void* workspace, size_t bytes, rgp_stream_t stream) {
+  RGP_REQUIRE(g && workspace, "rgp_grcn_bind_workspace: null argument");
+  if (bytes < g->ws_bytes) return set_err(RGP_EWORKSPACE, "workspace %zu < required %zu bytes", bytes, g->ws_bytes);
+  RGP_REQUIRE(((size_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  g->ws = (char*)workspace;
+  g->weights_set = false;
+  // zero everything once: halos of E / Hp / RHp / Hbn / D1 / D2 stay zero because
+  // epilogues only ever write interiors.
+  RGP_HIP(hipMemsetAsync(g->ws, 0, g->ws_bytes, s));
+  for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3}) RGP_TRY(upload_desc(*d, g->ws, s));
+  for (ConvDesc& d : g->d1) RGP_TRY(upload_desc(d, g->ws, s));
+  for (ConvDesc& d : g->d2) RGP_TRY(upload_desc(d, g->ws, s));
+  auto up = [&](const std::vector<int>& t, size_t off) -> int {
+    RGP_HIP(hipMemcpyAsync(g->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
+    return RGP_OK;
+  };
+  RGP_TRY(up(g->tab_pad9_P, g->o_pad9_P)); RGP_TRY(up(g->tab_pad9_S, g->o_pad9_S));
+  RGP_TRY(up(g->tab_pad27, g->o_pad27)); RGP_TRY(up(g->tab_pad55, g->o_pad55));
+  RGP_TRY(up(g->tab_lin49_3S, g->o_lin49_3S)); RGP_TRY(up(g->tab_lin49_S, g->o_lin49_S));
+  return RGP_OK;
+}
+
+int rgp_grcn_set_weights(rgp_grcn_t* g, const rgp_grcn_weights* w, rgp_stream_t stream) {
+  RGP_REQUIRE(g && w, "rgp_grcn_set_weights: null argument");
+  if (!g->ws) return set_err(RGP_EWORKSPACE, "rgp_grcn: workspace not bound");
+  const float* const* ptrs = (const float* const*)w;
+  for (size_t i = 0; i < sizeof(rgp_grcn_weights) / sizeof(float*); ++i)
+    RGP_REQUIRE(ptrs[i], "rgp_grcn_set_weights: weight pointer %zu is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s) : set_weights_impl<float>(g, w, s);
+}
+
+int rgp_proj_fwd(rgp_grcn_t* g, const float* c3d_input, rgp_stream_t stream) {
+  RGP_TRY(check_ready(g));
+  RGP_REQUIRE(c3d_input, "rgp_proj_fwd: null input");
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? proj_impl<bf16_t>(g, c3d_input, nullptr, s) : proj_impl<float>(g, c3d_input, nullptr, s);
+}
+
+int rgp_convgru_xconv_fwd(rgp_grcn_t* g, rgp_stream_t stream) {
+  RGP_TRY(check_ready(g));
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? xconv_impl<bf16_t>(g, s) : xconv_impl<float>(g, s);
+}
+
+int rgp_convgru_seq_fwd(rgp_grcn_t* g, rgp_stream_t stream) {
+  RGP_TRY(check_ready(g));
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? seq_impl<bf16_t>(g, s) : seq_impl<float>(g, s);
+}
+
+int rgp_head_fwd(rgp_grcn_t* g, float* logits, rgp_stream_t stream) {
+  RGP_TRY(check_ready(g));
+  RGP_REQUIRE(logits, "rgp_head_fwd: null logits");
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? head_impl<bf16_t>(g, logits, s) : head_impl<float>(g, logits, s);
+}
+
+static int grcn_tail(rgp_grcn_t* g, float* logits, float* probs, rgp_stream_t stream) {
+  RGP_TRY(rgp_convgru_xconv_fwd(g, stream));
+  RGP_TRY(rgp_convgru_seq_fwd(g, stream));
+  RGP_TRY(rgp_head_fwd(g, logits, stream));
+  if (probs) RGP_TRY(rgp_softmax_xent_fwd(logits, nullptr, probs, nullptr, nullptr, g->F, 2401, stream));
+  return RGP_OK;
+}
+
+int rgp_grcn_forward(rgp_grcn_t* g, const float* c3d_input, float* logits, float* probs, rgp_stream_t stream) {
+  RGP_TRY(rgp_proj_fwd(g, c3d_input, stream));
+  return grcn_tail(g, logits, probs, stream);
+}
+
+int rgp_grcn_forward_rows(rgp_grcn_t* g, const void* c3d_rows, float* logits, float* probs, rgp_stream_t stream) {
+  RGP_TRY(check_ready(g));
+  RGP_REQUIRE(c3d_rows && logits, "rgp_grcn_forward_rows: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  RGP_TRY(g->dtype == RGP_BF16 ? proj_impl<bf16_t>(g, nullptr, c3d_rows, s) : proj_impl<float>(g, nullptr, c3d_rows, s));
+  return grcn_tail(g, logits, probs, stream);
+}
+
+struct BufView {
+  size_t off; size_t tab; int rows, C; long long img_stride; long long imgs; bool f32;
+};
+
+static bool find_view(const rgp_grcn* g, const char* name, BufView& v) {
+  const int S = g->S, P = g->P;
+  const std::string n(name ? name : "");
+  if (n == "c3d_embedded") v = {g->E.off, g->o_pad9_P, 49, P, 81LL * P, g->F, false};
+  else if (n == "xpre") v = {g->xpre.off, g->o_lin49_3S, 49, 3 * S, 49LL * 3 * S, g->F, true};
+  else if (n == "bn") v = {g->hbn.off, g->o_pad9_S, 49, S, 81LL * S, g->F, false};
+  else if (n == "d1") v = {g->D1.off, g->o_pad27, 529, 64, 27LL * 27 * 64, g->F, false};
+  else if (n == "d2") v = {g->D2.off, g->o_pad55, 2401, 32, 55LL * 55 * 32, g->F, false};
+  else if (n == "u") v = {g->uall.off, g->o_lin49_S, 49, S, 49LL * S, (long long)g->T * g->B, true};
+  else if (n == "r" && g->save) v = {g->rall.off, g->o_lin49_S, 49, S, 49LL * S, (long long)g->T * g->B, true};
+  else if (n == "c" && g->save) v = {g->call.off, g->o_lin49_S, 49, S, 49LL * S, (long long)g->T * g->B, true};
+  else if (n == "h_all") v = {g->hall.off + (size_t)g->B * 49 * S * 4, g->o_lin49_S, 49, S, 49LL * S, (long long)g->T * g->B, true};
+  else return false;
+  return true;
+}
+
+size_t rgp_grcn_buffer_elems(const rgp_grcn_t* g, const char* name) {
+  BufView v;
+  if (!g) return 0;
+  if (name && std::string(name) == "rcn_outputs") return (size_t)g->F * 49 * g->S;
+  if (!find_view(g, name, v)) return 0;
+  return (size_t)v.imgs * v.rows * v.C;
+}
+
+// [T,B,49,S] -> [B,T,49,S]
+static __global__ void tb_to_bt_kernel(const float* __restrict__ src, float* __restrict__ dst, int T_, int B_, long long inner) {
+  const long long total = (long long)T_ * B_ * inner;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long in = i % inner;
+    const int t = (int)((i / inner) % T_);
+    const int b = (int)(i / (inner * T_));
+    dst[i] = src[((long long)t * B_ + b) * inner + in];
+  }
+}
+
+int rgp_grcn_read_buffer(rgp_grcn_t* g, const char* name, float* dst, rgp_stream_t stream) {
+  RGP_REQUIRE(g && g->ws && name && dst, "rgp_grcn_read_buffer: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (std::string(name) == "rcn_outputs") {   // h_1..h_T as [B,T,7,7,S] (gaze_grcn.py:288)
+    const float* src = (const float*)(g->ws + g->hall.off) + (size_t)g->B * 49 * g->S;
+    tb_to_bt_kernel<<<1024, 256, 0, s>>>(src, dst, g->T, g->B, 49LL * g->S);
+    RGP_HIP(hipGetLastError());
+    return RGP_OK;
+  }
+  BufView v;
+  if (!find_view(g, name, v)) return set_err(RGP_EINVAL, "rgp_grcn_read_buffer: unknown buffer '%s'", name);
+  const long long total = v.imgs * v.rows * v.C;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  const int* tab = (const int*)(g->ws + v.tab);
+  if (v.f32) unpad_kernel<float><<<blocks, 256, 0, s>>>((const float*)(g->ws + v.off), dst, tab, v.rows, v.C, v.img_stride, total);
+  else if (g->dtype == RGP_BF16) unpad_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)(g->ws + v.off), dst, tab, v.rows, v.C, v.img_stride, total);
+  else unpad_kernel<float><<<blocks, 256, 0, s>>>((const float*)(g->ws + v.off), dst, tab, v.rows, v.C, v.img_stride, total);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+}  // extern "C"

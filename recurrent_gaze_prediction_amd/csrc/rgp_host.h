@@ -1,0 +1,184 @@
+// Host-side plumbing shared by the plan objects: error reporting, workspace arena,
+// offset-table construction and the igemm launch dispatcher.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rgp.h"
+#include "igemm.hip.h"
+#include "kernels_misc.hip.h"
+
+namespace rgp {
+
+extern thread_local char g_err[512];
+int set_err(int code, const char* fmt, ...);
+
+#define RGP_HIP(call)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) return set_err(RGP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                         __FILE__, __LINE__);                                          \
+  } while (0)
+#define RGP_TRY(call)          \
+  do {                         \
+    int r_ = (call);           \
+    if (r_ != RGP_OK) return r_; \
+  } while (0)
+#define RGP_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return set_err(RGP_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  }
+};
+
+inline int esize(int dtype) { return dtype == RGP_BF16 ? 2 : 4; }
+inline int bke(int dtype) { return dtype == RGP_BF16 ? 64 : 32; }
+
+// One implicit-GEMM problem: offset tables, K schedule and filter packing recipe.
+struct ConvDesc {
+  // geometry
+  int Mw = 0, N = 0, K = 0, nk = 0, G = 1, P = 1;
+  long long in_img_stride = 0, out_img_stride = 0;
+  std::vector<int> in_tab, out_tab, koff;
+  // filter packing: dst[n][tap*cin_k + c] = src[tap_src[tap]*s_tap + n*s_n + c*s_c]
+  std::vector<int> tap_src;
+  int pack_taps = 0, cin_k = 0, cin_src = 0;
+  long long s_tap = 0, s_n = 0, s_c = 0;
+  // workspace offsets (bytes)
+  size_t in_tab_off = 0, out_tab_off = 0, koff_off = 0, tap_src_off = 0, w_off = 0;
+  int n_pad() const { return (int)align_up((size_t)N, 128); }
+  size_t w_bytes(int dtype) const { return (size_t)n_pad() * K * esize(dtype); }
+  void reserve(Arena& a, int dtype) {
+    in_tab_off = a.take(in_tab.size() * 4);
+    out_tab_off = a.take(out_tab.size() * 4);
+    koff_off = a.take(koff.size() * 4);
+    tap_src_off = a.take(tap_src.size() * 4);
+    w_off = a.take(w_bytes(dtype));
+  }
+};
+
+// K schedule for taps of `cin` contiguous elements each: chunks of BKE elements.
+// If cin < BKE several taps share one 128-byte chunk (G of them); the tap list is
+// padded with zero-weight taps to a multiple of G.  Fills koff, K, nk, G and the
+// packing tap list (tap_src = index into the filter's own tap order, -1 = zero).
+inline bool build_k_schedule(ConvDesc& d, const std::vector<int>& tapoff, const std::vector<int>& tap_filter_idx,
+                             int cin, int dtype) {
+  const int B = bke(dtype);
+  d.koff.clear();
+  d.tap_src = tap_filter_idx;
+  int ntaps = (int)tapoff.size();
+  std::vector<int> offs = tapoff;
+  if (cin >= B) {
+    if (cin % B) return false;
+    d.G = 1;
+    for (int t = 0; t < ntaps; ++t)
+      for (int c = 0; c < cin / B; ++c) d.koff.push_back(offs[t] + c * B);
+  } else {
+    if (B % cin) return false;
+    d.G = B / cin;
+    if (d.G != 2 && d.G != 4) return false;
+    while (ntaps % d.G) {
+      offs.push_back(offs[0]);
+      d.tap_src.push_back(-1);
+      ++ntaps;
+    }
+    d.koff = offs;
+  }
+  d.pack_taps = ntaps;
+  d.cin_k = cin;
+  d.cin_src = cin;
+  d.K = ntaps * cin;
+  d.nk = d.K / B;
+  return true;
+}
+
+int upload_desc(const ConvDesc& d, char* ws, hipStream_t s);
+
+template <typename T>
+int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int row0, hipStream_t s) {
+  const long long total = (long long)n_rows * d.pack_taps * d.cin_k;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+  pack_filter_kernel<T><<<blocks, 256, 0, s>>>(src, (T*)(ws + d.w_off), (const int*)(ws + d.tap_src_off), d.pack_taps,
+                                               d.cin_k, d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_n, d.s_c);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+// ---- launch dispatch -------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
+int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi>;
+  constexpr int smem = IgemmSmem<BM, BN>::BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  const int n_mt = (p.M + BM - 1) / BM, n_nt = (p.N + BN - 1) / BN;
+  kern<<<dim3(n_mt * n_nt), dim3(WM * WN * 64), smem, s>>>(p, e);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+// Tile choice by output width: 128x128 (2x2 waves of 64x64) for N >= 128,
+// 128x64 (2x2 waves of 64x32) for N in (32, 64], 128x32 (4x1 waves of 32x32) below.
+template <typename T, int G, int P, class Epi>
+int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
+  if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
+  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s);
+  if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s);
+  return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s);
+}
+
+inline IgemmParams make_params(const ConvDesc& d, const void* A, char* ws, int n_img) {
+  IgemmParams p;
+  p.A = A;
+  p.W = ws + d.w_off;
+  p.in_tab = (const int*)(ws + d.in_tab_off);
+  p.koff = (const int*)(ws + d.koff_off);
+  p.in_img_stride = d.in_img_stride;
+  p.Mw = d.Mw;
+  p.M = d.Mw * n_img;
+  p.N = d.N;
+  p.K = d.K;
+  p.nk = d.nk;
+  return p;
+}
+
+inline EpiParams make_epi(const ConvDesc& d, void* out, char* ws) {
+  EpiParams e;
+  memset(&e, 0, sizeof(e));
+  e.out = out;
+  e.out_tab = (const int*)(ws + d.out_tab_off);
+  e.out_img_stride = d.out_img_stride;
+  return e;
+}
+
+// dst[img][i][c] (fp32, dense) = src[img*img_stride + tab[i] + c] for c < C.
+template <typename T>
+__global__ __launch_bounds__(256) void unpad_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                    const int* __restrict__ tab, int rows, int C, long long img_stride,
+                                                    long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int r = (int)((i / C) % rows);
+    const long long img = i / ((long long)C * rows);
+    dst[i] = Elem<T>::from(src[img * img_stride + tab[r] + c]);
+  }
+}
+
+}  // namespace rgp

@@ -1,0 +1,184 @@
+"""Device-side engines: thin owners of a librgp_hip plan + its workspace.
+
+PyTorch is plumbing only here (device memory, streams); all arithmetic happens in
+the HIP kernels behind the C ABI (include/rgp.h).  These classes play the role of
+the reference's ``tf.Session`` + graph for the gaze path (models/gaze_rnn.py:523-531).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+GRCN_PARAM_TO_FIELD = {   # reference TF variable name -> rgp_grcn_weights field
+    'proj_c3d_W': 'proj_c3d_W', 'proj_c3d_b': 'proj_c3d_b',
+    'GRU_Conv_Wz': 'gru_Wz', 'GRU_Conv_Uz': 'gru_Uz', 'GRU_Conv_Wr': 'gru_Wr', 'GRU_Conv_Ur': 'gru_Ur',
+    'GRU_Conv_W': 'gru_W', 'GRU_Conv_U': 'gru_U', 'bn_gamma': 'bn_gamma', 'bn_beta': 'bn_beta',
+    'weight1': 'up_weight1', 'weight2': 'up_weight2', 'weight3': 'up_weight3', 'out_W': 'out_W', 'out_b': 'out_b',
+}
+C3D_LAYER_NAMES = ('conv1a', 'conv2a', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5a', 'conv5b')
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise _lib.RgpError('no HIP device visible: the gaze path runs only on the GPU (no CPU fallback)')
+    return torch.device(device)
+
+
+def _as_dev_f32(x, device):
+    t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class GrcnEngine(object):
+    """gaze_grcn graph (models/gaze_grcn.py:173-376) at fixed (B, T, P, S, dtype)."""
+
+    def __init__(self, batch, n_steps, dim_proj=512, dim_state=128, dtype='bf16', save_for_backward=False,
+                 device='cuda:0'):
+        self.lib = _lib.load()
+        self.device = _require_gpu(device)
+        self.B, self.T, self.P, self.S = int(batch), int(n_steps), int(dim_proj), int(dim_state)
+        self.dtype = dtype
+        self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_create(ctypes.byref(self._h), self.B, self.T, self.P, self.S,
+                                                _lib.DTYPES[dtype], int(bool(save_for_backward))))
+            nbytes = self.lib.rgp_grcn_workspace_bytes(self._h)
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.rgp_grcn_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
+        self.weights = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self.lib.rgp_grcn_destroy(h)
+
+    def set_weights(self, params):
+        """params: dict keyed by the reference's TF variable names -> array/tensor (fp32)."""
+        w = {k: _as_dev_f32(params[k], self.device) for k in GRCN_PARAM_TO_FIELD}
+        assert tuple(w['bn_gamma'].shape) == (self.T, self.S), 'one batch-norm layer per timestep (SURVEY 9-Q1)'
+        st = _lib.GrcnWeights()
+        for k, f in GRCN_PARAM_TO_FIELD.items():
+            setattr(st, f, w[k].data_ptr())
+        self.weights = w                    # keep alive: the plan holds raw pointers to biases / BN
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def forward(self, c3d_input, want_probs=True, out_logits=None, out_probs=None):
+        """c3d_input [B,T,1024,7,7] fp32 device tensor -> (logits, probs) [B,T,49,49]."""
+        x = c3d_input
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert tuple(x.shape) == (self.B, self.T, 1024, 7, 7), tuple(x.shape)
+        logits = out_logits if out_logits is not None else torch.empty(self.B, self.T, 49, 49, device=self.device)
+        probs = None
+        if want_probs:
+            probs = out_probs if out_probs is not None else torch.empty_like(logits)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_forward(self._h, _ptr(x), _ptr(logits), _ptr(probs), _stream_ptr(self.device)))
+        return logits, probs
+
+    def forward_rows(self, rows, want_probs=True, out_logits=None, out_probs=None):
+        """rows: conv5b rows from C3DEngine.forward (operand dtype, [B*T*49, 1024])."""
+        assert rows.is_cuda and rows.dtype == self.torch_dtype and rows.numel() == self.B * self.T * 49 * 1024
+        logits = out_logits if out_logits is not None else torch.empty(self.B, self.T, 49, 49, device=self.device)
+        probs = None
+        if want_probs:
+            probs = out_probs if out_probs is not None else torch.empty_like(logits)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_forward_rows(self._h, _ptr(rows), _ptr(logits), _ptr(probs),
+                                                      _stream_ptr(self.device)))
+        return logits, probs
+
+    def read_buffer(self, name):
+        n = self.lib.rgp_grcn_buffer_elems(self._h, name.encode())
+        if n == 0:
+            raise _lib.RgpError('unknown intermediate %r' % name)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_read_buffer(self._h, name.encode(), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+
+def softmax_xent(logits, labels=None, want_probs=True):
+    """Per-frame softmax / cross entropy (model_util.py:61-72; gaze_rnn.py:390-407).
+    logits [..., H, W] fp32 device tensor -> (probs, frame_loss, loss)."""
+    lib = _lib.load()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous()
+    npix = logits.shape[-1] * logits.shape[-2]
+    frames = logits.numel() // npix
+    probs = torch.empty_like(logits) if want_probs else None
+    frame_loss = loss = None
+    if labels is not None:
+        assert labels.shape == logits.shape and labels.dtype == torch.float32 and labels.is_contiguous()
+        frame_loss = torch.empty(frames, device=logits.device)
+        loss = torch.empty(1, device=logits.device)
+    with torch.cuda.device(logits.device):
+        _lib.check(lib.rgp_softmax_xent_fwd(_ptr(logits), _ptr(labels), _ptr(probs), _ptr(frame_loss), _ptr(loss),
+                                            frames, npix, _stream_ptr(logits.device)))
+    return probs, frame_loss, loss
+
+
+class C3DEngine(object):
+    """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
+
+    def __init__(self, max_windows, dtype='bf16', device='cuda:0'):
+        self.lib = _lib.load()
+        self.device = _require_gpu(device)
+        self.max_windows = int(max_windows)
+        self.dtype = dtype
+        self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_create(ctypes.byref(self._h), self.max_windows, _lib.DTYPES[dtype]))
+            nbytes = self.lib.rgp_c3d_workspace_bytes(self._h)
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.rgp_c3d_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
+        self.weights = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self.lib.rgp_c3d_destroy(h)
+
+    def set_weights(self, params):
+        """params: {'conv1a_w': [3,3,3,Cin,Cout], 'conv1a_b': [Cout], ...} fp32."""
+        w = {}
+        st = _lib.C3DWeights()
+        for i, name in enumerate(C3D_LAYER_NAMES):
+            w[name + '_w'] = _as_dev_f32(params[name + '_w'], self.device)
+            w[name + '_b'] = _as_dev_f32(params[name + '_b'], self.device)
+            st.w[i] = w[name + '_w'].data_ptr()
+            st.b[i] = w[name + '_b'].data_ptr()
+        self.weights = w
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def forward(self, video, want_features=True, want_rows=False, out_rows=None):
+        """video [n,16,112,112,3] fp32 device tensor -> (features [n,1024,7,7] fp32, rows)."""
+        assert video.is_cuda and video.dtype == torch.float32 and video.is_contiguous()
+        assert tuple(video.shape[1:]) == (16, 112, 112, 3), tuple(video.shape)
+        n = video.shape[0]
+        feats = torch.empty(n, 1024, 7, 7, device=self.device) if want_features else None
+        rows = out_rows
+        if want_rows and rows is None:
+            rows = torch.empty(n * 49, 1024, dtype=self.torch_dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_forward(self._h, _ptr(video), n, _ptr(feats), _ptr(rows), _stream_ptr(self.device)))
+        return feats, rows
+
+    def read_layer(self, layer, n_windows):
+        n = self.lib.rgp_c3d_layer_elems(self._h, layer, n_windows)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_read_layer(self._h, layer, n_windows, _ptr(out), _stream_ptr(self.device)))
+        return out

@@ -1,0 +1,54 @@
+"""GPU parity: the HIP gaze_grcn path (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref
+from recurrent_gaze_prediction_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+# tolerances: max-abs error relative to the max-abs of the oracle tensor.
+# f32 path = exact fp32 FMA chains (v_mfma_f32_16x16x4_f32) vs a float64 oracle;
+# bf16 path = bf16 MFMA operands with fp32 accumulate/state (<= 2e-2 on logits).
+TOL = {'f32': 2e-5, 'bf16': 2e-2}
+# hidden states at gru_std=0.05 sit in the saturated part of tanh/sigmoid (pre-activation
+# std ~5), where one bf16 ulp of the operands moves single elements by a few 1e-2: bound
+# the worst element looser and the RMS tighter.
+TOL_H_MAX = {'f32': 5e-5, 'bf16': 6e-2}
+TOL_H_RMS = {'f32': 1e-5, 'bf16': 1e-2}
+
+
+def rel_err(a, ref):
+    a = np.asarray(a, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def oracle_forward(x, p):
+    pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+    logits, hs, emb = torch_ref.grcn_forward(torch.tensor(x, dtype=torch.float64), pt, want_hidden=True)
+    return logits.numpy(), hs.numpy(), emb.numpy()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,T,P,S', [(2, 3, 512, 128), (3, 2, 64, 64)])
+def test_grcn_forward_matches_oracle(gpu, dtype, B, T, P, S):
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    p = syn.grcn_params(11, T, P, S, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(12, B, T)
+    ref_logits, ref_h, ref_emb = oracle_forward(x, p)
+    eng = GrcnEngine(B, T, P, S, dtype=dtype, device=gpu)
+    eng.set_weights(p)
+    logits, probs = eng.forward(torch.tensor(x, device=gpu))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    emb = eng.read_buffer('c3d_embedded').cpu().numpy().reshape(ref_emb.shape)
+    assert rel_err(emb, ref_emb) < tol, 'projection'
+    h = eng.read_buffer('rcn_outputs').cpu().numpy().reshape(ref_h.shape)
+    assert rel_err(h, ref_h) < TOL_H_MAX[dtype], 'ConvGRU states (max)'
+    assert np.sqrt(((h - ref_h) ** 2).mean()) / np.sqrt((ref_h ** 2).mean()) < TOL_H_RMS[dtype], 'ConvGRU states (rms)'
+    assert rel_err(logits.cpu().numpy(), ref_logits) < tol, 'logits'
+    ref_probs = torch_ref.softmax_maps(torch.tensor(ref_logits)).numpy()
+    assert rel_err(probs.cpu().numpy(), ref_probs) < tol, 'softmax maps'
+    assert np.allclose(probs.cpu().numpy().reshape(B, T, -1).sum(-1), 1.0, atol=1e-5)
