@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/sec of 49x49 saliency maps, gaze_grcn, 16-step clips.
+
+One step = one pass of the whole hot path over one batch of synthetic clips that is
+already resident in HBM:
+
+  e2e  (default)  video windows [B*T,16,112,112,3] fp32 -> C3D conv1a..conv5b ->
+                  1024->512 projection -> ConvGRU (T steps) -> transposed-conv head ->
+                  per-frame softmax  =>  B*T maps of 49x49
+  head            c3d_input [B,T,1024,7,7] fp32 (what the reference's TF graph is fed,
+                  models/gaze_rnn.py:118-121) -> the same head
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` ; for N>1 it is
+launched by torch.distributed.run with one rank per GPU.  Clips shard data-parallel
+across ranks with no data-path collective (inference: SURVEY.md 8e "replicas only"),
+so scaling is weak: every rank runs B clips.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from recurrent_gaze_prediction_amd import synthetic as syn  # noqa: E402
+from recurrent_gaze_prediction_amd.engine import C3DEngine, GrcnEngine  # noqa: E402
+
+# forward FLOPs (2*MAC), reference op sequence, no folding
+C3D_LAYERS = [('conv1a', 3, 64, 16, 112), ('conv2a', 64, 128, 16, 56), ('conv3a', 128, 256, 8, 28),
+              ('conv3b', 256, 256, 8, 28), ('conv4a', 256, 512, 4, 14), ('conv4b', 512, 512, 4, 14),
+              ('conv5a', 512, 512, 2, 7), ('conv5b', 512, 512, 2, 7)]
+C3D_FLOPS = {n: 2.0 * d * h * h * 27 * ci * co for n, ci, co, d, h in C3D_LAYERS}     # per window
+HEAD_FLOPS = {'proj': 51.38e6, 'xconv': 173.41e6, 'convgru_seq': 43.35e6, 'head': 20.07e6 + 54.17e6 + 90.35e6 + 0.06e6}
+HEAD_FLOPS_FRAME = 432.79e6
+C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
+# kernel instantiation that executes each C3D layer (template igemm_kernel<T,BM,BN,WM,WN,G,P,Epi>)
+C3D_KERNEL_GROUP = {'conv1a': 'igemm<128x64,G4,pool4>', 'conv2a': 'igemm<128x128,G1,pool8>',
+                    'conv3b': 'igemm<128x128,G1,pool8>', 'conv4b': 'igemm<128x128,G1,pool8>',
+                    'conv3a': 'igemm<128x128,G1,pool1>', 'conv4a': 'igemm<128x128,G1,pool1>',
+                    'conv5a': 'igemm<128x128,G1,pool1>', 'conv5b': 'igemm<128x128,G1,pool1>'}
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', choices=['e2e', 'head'], default='e2e')
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--n-steps', type=int, default=16, help='RNN timesteps T per clip')
+    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
+    ap.add_argument('--c3d-chunk', type=int, default=128, help='windows per C3D launch chain')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
+    ap.add_argument('--cpu-threads', type=int, default=16, help='host threads for the CPU baseline')
+    return ap.parse_args()
+
+
+def cpu_baseline(args, budget_s):
+    """Reference-equivalent CPU restatement (TF1.x unavailable offline): the oracle's
+    torch-CPU fp32 graph, unfused and T-unrolled like the TF graph, on the host cores.
+    Bounded sample: whole clips (T frames each) until ~budget_s seconds are spent."""
+    from oracle import torch_ref
+    # the GPU box gives one GPU's job a 16-core CPU share; more threads than that only
+    # oversubscribe (measured: 256 threads ran the 7x7 convs 20x slower than 16)
+    torch.set_num_threads(min(os.cpu_count() or 1, args.cpu_threads))
+    T = args.n_steps
+    hp = {k: torch.tensor(v) for k, v in syn.grcn_params(1, T).items()}
+    cp = {k: torch.tensor(v) for k, v in syn.c3d_params(2).items()}
+    frames, t_c3d, t_head = 0, 0.0, 0.0
+    t_start = time.time()
+    clip = 0
+    with torch.no_grad():
+        while True:
+            if args.workload == 'e2e':
+                v = torch.tensor(syn.video_windows(100 + clip, T))
+                t0 = time.time()
+                feat = torch_ref.c3d_forward(v, cp)                      # [T,1024,7,7]
+                t_c3d += time.time() - t0
+                x = feat.reshape(1, T, 1024, 7, 7)
+            else:
+                x = torch.tensor(syn.c3d_features(100 + clip, 1, T))
+            t0 = time.time()
+            torch_ref.softmax_maps(torch_ref.grcn_forward(x, hp))
+            t_head += time.time() - t0
+            frames += T
+            clip += 1
+            el = time.time() - t_start
+            if el >= budget_s or el + el / clip > budget_s * 1.5:
+                break
+    tot = t_c3d + t_head
+    return {'value': frames / tot, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d clip(s) of %d frames (%s), oracle/torch_ref.py fp32 on host cores, %.1f s '
+                      '(C3D %.1f s, head %.2f s)' % (clip, T, args.workload, tot, t_c3d, t_head)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
+
+    head = GrcnEngine(B, T, dtype=args.dtype, device=dev)
+    head.set_weights(syn.grcn_params(1, T))
+    logits = torch.empty(B, T, 49, 49, device=dev)
+    probs = torch.empty_like(logits)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    if args.workload == 'e2e':
+        c3d = C3DEngine(min(args.c3d_chunk, F), dtype=args.dtype, device=dev)
+        c3d.set_weights(syn.c3d_params(2))
+        video = torch.rand(F, 16, 112, 112, 3, device=dev, generator=g) - 0.5   # U(0,1)-0.5, resident in HBM
+        rows = torch.empty(F * 49, 1024, dtype=c3d.torch_dtype, device=dev)
+
+        def step():
+            c3d.forward(video, want_features=False, want_rows=True, out_rows=rows)
+            head.forward_rows(rows, out_logits=logits, out_probs=probs)
+    else:
+        c3d = None
+        x = torch.relu(torch.randn(B, T, 1024, 7, 7, device=dev, generator=g))    # conv5b is post-ReLU
+
+        def step():
+            head.forward(x, out_logits=logits, out_probs=probs)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    head.profile(True)
+    if c3d is not None:
+        c3d.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    hprof = head.profile_read()
+    cprof = c3d.profile_read() if c3d is not None else {}
+    assert torch.isfinite(probs).all(), 'non-finite saliency maps'
+
+    if rank == 0:
+        frames_total = world * F * args.steps
+        value = frames_total / elapsed
+        # ---- roofline of the dominant kernel (HIP-event time on the launch stream, timed region)
+        if c3d is not None:
+            groups = {}
+            for name, _, _, _, _ in C3D_LAYERS:
+                ms, calls = cprof[name]
+                grp = groups.setdefault(C3D_KERNEL_GROUP[name], [0.0, 0.0, 0])
+                grp[0] += ms
+                grp[1] += C3D_FLOPS[name] * F * args.steps          # flops executed in the timed region
+                grp[2] += calls
+            kname, (ms, flops, calls) = max(groups.items(), key=lambda kv: kv[1][0])
+        else:
+            kname, (ms, calls) = max(((k, v) for k, v in hprof.items() if k != 'softmax'), key=lambda kv: kv[1][0])
+            flops = HEAD_FLOPS[kname] * F * args.steps
+        achieved = flops / (ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': kname,
+                    'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
+                    'algorithmic_gflop_per_launch': round(flops / max(calls, 1) / 1e9, 3)}
+        flops_frame = HEAD_FLOPS_FRAME + (C3D_FLOPS_FRAME if c3d is not None else 0.0)
+        out = {
+            'metric': 'frames/sec (49x49 saliency maps), gaze_grcn 16-frame clips',
+            'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': ('gaze_grcn end-to-end: synthetic 16x112x112x3 windows -> C3D conv1a-5b -> '
+                                    '1024->512 proj -> ConvGRU(512->128, 7x7) -> deconv head -> 49x49 softmax maps'
+                                    if c3d is not None else
+                                    'gaze_grcn head on precomputed C3D conv5b features [B,T,1024,7,7]'),
+                       'clips_per_gpu': B, 'n_lstm_steps': T, 'frames_per_step_per_gpu': F,
+                       'parallelism': 'dp%d (clip-sharded replicas, no collective)' % world,
+                       'weights': 'random init (reference initialisers), GRU filters std 0.05'},
+            'algorithmic_tflops': round(value * flops_frame / 1e12, 2),
+            'stage_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in list(cprof.items()) + list(hprof.items())},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+            out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

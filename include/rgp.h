@@ -106,6 +106,15 @@ size_t rgp_grcn_buffer_elems(const rgp_grcn_t* plan, const char* name);
 int rgp_softmax_xent_fwd(const float* logits, const float* labels, float* probs, float* frame_loss, float* loss,
                          int frames, int npix, rgp_stream_t stream);
 
+/* Stage timing (HIP events recorded on the caller's stream around each stage launch
+ * group; costs two hipEventRecord per stage).  Stages: 0 proj (incl. transpose),
+ * 1 xconv, 2 convgru sequence, 3 head (transposed convs), 4 softmax.
+ * rgp_grcn_profile_read synchronises on the recorded events, writes the accumulated
+ * milliseconds and launch-group counts since the last read, and resets them. */
+#define RGP_GRCN_STAGES 5
+int rgp_grcn_profile_enable(rgp_grcn_t* plan, int enable);
+int rgp_grcn_profile_read(rgp_grcn_t* plan, double ms[RGP_GRCN_STAGES], long long calls[RGP_GRCN_STAGES]);
+
 /* ------------------------------------------------------------------ C3D conv stack */
 typedef struct rgp_c3d rgp_c3d_t;
 
@@ -130,6 +139,12 @@ int rgp_c3d_forward(rgp_c3d_t* plan, const float* video, int n_windows, float* f
 /* Copies layer i's (0..7) pooled, post-ReLU output, un-padded fp32 NDHWC, into dst. */
 int rgp_c3d_read_layer(rgp_c3d_t* plan, int layer, int n_windows, float* dst, rgp_stream_t stream);
 size_t rgp_c3d_layer_elems(const rgp_c3d_t* plan, int layer, int n_windows);
+
+/* Per-layer timing, as rgp_grcn_profile_*: index 0..7 = conv1a..conv5b (one fused
+ * conv+bias+ReLU+pool kernel launch each), 8 = video_prep. */
+#define RGP_C3D_STAGES 9
+int rgp_c3d_profile_enable(rgp_c3d_t* plan, int enable);
+int rgp_c3d_profile_read(rgp_c3d_t* plan, double ms[RGP_C3D_STAGES], long long calls[RGP_C3D_STAGES]);
 
 #ifdef __cplusplus
 }

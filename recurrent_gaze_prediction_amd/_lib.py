@@ -7,6 +7,12 @@ this module raises.  Build it with ``python -c "import __graft_entry__ as g; g.b
 import ctypes
 import os
 
+# torch must be imported BEFORE librgp_hip.so is dlopen'ed: the library's libamdhip64
+# dependency then resolves to the HIP runtime torch has already loaded, so device
+# pointers, streams and events are shared.  Loading it first would bring in a second
+# HIP runtime that sees no context ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librgp_hip.so')
 
 RGP_F32, RGP_BF16 = 0, 1
@@ -56,7 +62,13 @@ SIGNATURES = {
     'rgp_c3d_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'rgp_c3d_read_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'rgp_c3d_layer_elems': (c_size_t, [c_void_p, c_int, c_int]),
+    'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
+    'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
+    'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),
+    'rgp_c3d_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
 }
+GRCN_STAGES = ('proj', 'xconv', 'convgru_seq', 'head', 'softmax')
+C3D_STAGES = ('conv1a', 'conv2a', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5a', 'conv5b', 'video_prep')
 
 _lib = None
 

@@ -29,6 +29,7 @@ struct rgp_c3d {
   char* ws = nullptr;
   bool weights_set = false;
   const float* bias[8] = {nullptr};
+  StageProfiler prof;
 };
 
 namespace {
@@ -54,10 +55,16 @@ int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
 template <typename T>
 int forward_chunk(rgp_c3d* c, const float* video, int n, float* features, void* rows, hipStream_t s) {
   const long long npix = (long long)n * 16 * 112 * 112;
+  int pid = c->prof.begin(8, s);
   video_prep_kernel<T><<<(int)std::min<long long>((npix + 255) / 256, 65536), 256, 0, s>>>(
       video, (T*)(c->ws + c->act_off[0]), npix, 16, 112, 112);
   RGP_HIP(hipGetLastError());
-  for (int i = 0; i < 8; ++i) RGP_TRY(layer_dispatch<T>(c, i, n, s));
+  c->prof.end(pid, s);
+  for (int i = 0; i < 8; ++i) {
+    pid = c->prof.begin(i, s);
+    RGP_TRY(layer_dispatch<T>(c, i, n, s));
+    c->prof.end(pid, s);
+  }
   const T* r = (const T*)(c->ws + c->act_off[8]);
   if (rows) RGP_HIP(hipMemcpyAsync(rows, r, (size_t)n * 49 * 1024 * sizeof(T), hipMemcpyDeviceToDevice, s));
   if (features) {
@@ -194,6 +201,17 @@ int rgp_c3d_forward(rgp_c3d_t* c, const float* video, int n_windows, float* feat
     RGP_TRY(c->dtype == RGP_BF16 ? forward_chunk<bf16_t>(c, v, n, f, r, s) : forward_chunk<float>(c, v, n, f, r, s));
   }
   return RGP_OK;
+}
+
+int rgp_c3d_profile_enable(rgp_c3d_t* c, int enable) {
+  RGP_REQUIRE(c, "rgp_c3d_profile_enable: null plan");
+  c->prof.enabled = enable != 0;
+  return RGP_OK;
+}
+
+int rgp_c3d_profile_read(rgp_c3d_t* c, double ms[RGP_C3D_STAGES], long long calls[RGP_C3D_STAGES]) {
+  RGP_REQUIRE(c && ms && calls, "rgp_c3d_profile_read: null argument");
+  return c->prof.read(ms, calls, RGP_C3D_STAGES);
 }
 
 size_t rgp_c3d_layer_elems(const rgp_c3d_t* c, int layer, int n_windows) {

@@ -24,6 +24,7 @@ struct rgp_grcn {
   char* ws = nullptr;
   bool weights_set = false;
   const float *bn_gamma = nullptr, *bn_beta = nullptr, *proj_b = nullptr, *out_b = nullptr;
+  StageProfiler prof;
 };
 
 namespace {
@@ -359,33 +360,49 @@ int rgp_proj_fwd(rgp_grcn_t* g, const float* c3d_input, rgp_stream_t stream) {
   RGP_TRY(check_ready(g));
   RGP_REQUIRE(c3d_input, "rgp_proj_fwd: null input");
   hipStream_t s = (hipStream_t)stream;
-  return g->dtype == RGP_BF16 ? proj_impl<bf16_t>(g, c3d_input, nullptr, s) : proj_impl<float>(g, c3d_input, nullptr, s);
+  const int pid = g->prof.begin(0, s);
+  const int rc = g->dtype == RGP_BF16 ? proj_impl<bf16_t>(g, c3d_input, nullptr, s) : proj_impl<float>(g, c3d_input, nullptr, s);
+  g->prof.end(pid, s);
+  return rc;
 }
 
 int rgp_convgru_xconv_fwd(rgp_grcn_t* g, rgp_stream_t stream) {
   RGP_TRY(check_ready(g));
   hipStream_t s = (hipStream_t)stream;
-  return g->dtype == RGP_BF16 ? xconv_impl<bf16_t>(g, s) : xconv_impl<float>(g, s);
+  const int pid = g->prof.begin(1, s);
+  const int rc = g->dtype == RGP_BF16 ? xconv_impl<bf16_t>(g, s) : xconv_impl<float>(g, s);
+  g->prof.end(pid, s);
+  return rc;
 }
 
 int rgp_convgru_seq_fwd(rgp_grcn_t* g, rgp_stream_t stream) {
   RGP_TRY(check_ready(g));
   hipStream_t s = (hipStream_t)stream;
-  return g->dtype == RGP_BF16 ? seq_impl<bf16_t>(g, s) : seq_impl<float>(g, s);
+  const int pid = g->prof.begin(2, s);
+  const int rc = g->dtype == RGP_BF16 ? seq_impl<bf16_t>(g, s) : seq_impl<float>(g, s);
+  g->prof.end(pid, s);
+  return rc;
 }
 
 int rgp_head_fwd(rgp_grcn_t* g, float* logits, rgp_stream_t stream) {
   RGP_TRY(check_ready(g));
   RGP_REQUIRE(logits, "rgp_head_fwd: null logits");
   hipStream_t s = (hipStream_t)stream;
-  return g->dtype == RGP_BF16 ? head_impl<bf16_t>(g, logits, s) : head_impl<float>(g, logits, s);
+  const int pid = g->prof.begin(3, s);
+  const int rc = g->dtype == RGP_BF16 ? head_impl<bf16_t>(g, logits, s) : head_impl<float>(g, logits, s);
+  g->prof.end(pid, s);
+  return rc;
 }
 
 static int grcn_tail(rgp_grcn_t* g, float* logits, float* probs, rgp_stream_t stream) {
   RGP_TRY(rgp_convgru_xconv_fwd(g, stream));
   RGP_TRY(rgp_convgru_seq_fwd(g, stream));
   RGP_TRY(rgp_head_fwd(g, logits, stream));
-  if (probs) RGP_TRY(rgp_softmax_xent_fwd(logits, nullptr, probs, nullptr, nullptr, g->F, 2401, stream));
+  if (probs) {
+    const int pid = g->prof.begin(4, (hipStream_t)stream);
+    RGP_TRY(rgp_softmax_xent_fwd(logits, nullptr, probs, nullptr, nullptr, g->F, 2401, stream));
+    g->prof.end(pid, (hipStream_t)stream);
+  }
   return RGP_OK;
 }
 
@@ -398,8 +415,21 @@ int rgp_grcn_forward_rows(rgp_grcn_t* g, const void* c3d_rows, float* logits, fl
   RGP_TRY(check_ready(g));
   RGP_REQUIRE(c3d_rows && logits, "rgp_grcn_forward_rows: null argument");
   hipStream_t s = (hipStream_t)stream;
+  const int pid = g->prof.begin(0, s);
   RGP_TRY(g->dtype == RGP_BF16 ? proj_impl<bf16_t>(g, nullptr, c3d_rows, s) : proj_impl<float>(g, nullptr, c3d_rows, s));
+  g->prof.end(pid, s);
   return grcn_tail(g, logits, probs, stream);
+}
+
+int rgp_grcn_profile_enable(rgp_grcn_t* g, int enable) {
+  RGP_REQUIRE(g, "rgp_grcn_profile_enable: null plan");
+  g->prof.enabled = enable != 0;
+  return RGP_OK;
+}
+
+int rgp_grcn_profile_read(rgp_grcn_t* g, double ms[RGP_GRCN_STAGES], long long calls[RGP_GRCN_STAGES]) {
+  RGP_REQUIRE(g && ms && calls, "rgp_grcn_profile_read: null argument");
+  return g->prof.read(ms, calls, RGP_GRCN_STAGES);
 }
 
 struct BufView {

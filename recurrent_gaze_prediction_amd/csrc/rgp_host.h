@@ -168,6 +168,38 @@ inline EpiParams make_epi(const ConvDesc& d, void* out, char* ws) {
   return e;
 }
 
+// Stage timer: pairs of HIP events recorded on the launch stream, summed per stage at read().
+struct StageProfiler {
+  bool enabled = false;
+  struct Rec { hipEvent_t a, b; int stage; };
+  std::vector<Rec> pool;
+  size_t used = 0;
+  int begin(int stage, hipStream_t s) {
+    if (!enabled) return -1;
+    if (used == pool.size()) {
+      Rec r; r.stage = stage;
+      if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+      pool.push_back(r);
+    }
+    pool[used].stage = stage;
+    (void)hipEventRecord(pool[used].a, s);
+    return (int)used++;
+  }
+  void end(int id, hipStream_t s) { if (id >= 0) (void)hipEventRecord(pool[id].b, s); }
+  int read(double* ms, long long* calls, int nstages) {
+    for (int i = 0; i < nstages; ++i) { ms[i] = 0; calls[i] = 0; }
+    for (size_t i = 0; i < used; ++i) {
+      float t = 0.f;
+      RGP_HIP(hipEventSynchronize(pool[i].b));
+      RGP_HIP(hipEventElapsedTime(&t, pool[i].a, pool[i].b));
+      if (pool[i].stage < nstages) { ms[pool[i].stage] += t; calls[pool[i].stage] += 1; }
+    }
+    used = 0;
+    return RGP_OK;
+  }
+  ~StageProfiler() { for (auto& r : pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
+};
+
 // dst[img][i][c] (fp32, dense) = src[img*img_stride + tab[i] + c] for c < C.
 template <typename T>
 __global__ __launch_bounds__(256) void unpad_kernel(const T* __restrict__ src, float* __restrict__ dst,

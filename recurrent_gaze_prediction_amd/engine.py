@@ -108,6 +108,16 @@ class GrcnEngine(object):
             _lib.check(self.lib.rgp_grcn_read_buffer(self._h, name.encode(), _ptr(out), _stream_ptr(self.device)))
         return out
 
+    def profile(self, enable=True):
+        _lib.check(self.lib.rgp_grcn_profile_enable(self._h, int(enable)))
+
+    def profile_read(self):
+        """{stage: (total_ms, launch_groups)} since the last read (HIP events on the launch stream)."""
+        n = len(_lib.GRCN_STAGES)
+        ms, calls = (ctypes.c_double * n)(), (ctypes.c_longlong * n)()
+        _lib.check(self.lib.rgp_grcn_profile_read(self._h, ms, calls))
+        return {k: (ms[i], calls[i]) for i, k in enumerate(_lib.GRCN_STAGES)}
+
 
 def softmax_xent(logits, labels=None, want_probs=True):
     """Per-frame softmax / cross entropy (model_util.py:61-72; gaze_rnn.py:390-407).
@@ -182,3 +192,13 @@ class C3DEngine(object):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_c3d_read_layer(self._h, layer, n_windows, _ptr(out), _stream_ptr(self.device)))
         return out
+
+    def profile(self, enable=True):
+        _lib.check(self.lib.rgp_c3d_profile_enable(self._h, int(enable)))
+
+    def profile_read(self):
+        """{stage: (total_ms, launch_groups)} since the last read (HIP events on the launch stream)."""
+        n = len(_lib.C3D_STAGES)
+        ms, calls = (ctypes.c_double * n)(), (ctypes.c_longlong * n)()
+        _lib.check(self.lib.rgp_c3d_profile_read(self._h, ms, calls))
+        return {k: (ms[i], calls[i]) for i, k in enumerate(_lib.C3D_STAGES)}
