@@ -26,6 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from recurrent_gaze_prediction_amd import dist as rdist  # noqa: E402
 from recurrent_gaze_prediction_amd import synthetic as syn  # noqa: E402
 from recurrent_gaze_prediction_amd.engine import C3DEngine, GrcnEngine  # noqa: E402
 
@@ -101,18 +102,12 @@ def cpu_baseline(args, budget_s):
 
 def main():
     args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rank, local_rank, world = rdist.env_world()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    dist = rdist.init(backend='nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
     B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
 
     head = GrcnEngine(B, T, dtype=args.dtype, device=dev)
@@ -138,10 +133,7 @@ def main():
             head.forward(x, out_logits=logits, out_probs=probs)
 
     def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        rdist.barrier(dist, dev)
 
     for _ in range(args.warmup):
         step()
@@ -153,11 +145,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
     hprof = head.profile_read()
     cprof = c3d.profile_read() if c3d is not None else {}
     assert torch.isfinite(probs).all(), 'non-finite saliency maps'

@@ -1,0 +1,197 @@
+"""Mirror of /root/reference/models/gaze_rnn.py: GRUModelConfig, CONSTANTS and the
+GazePredictionGRU harness (build_model / single_step / generate / evaluate).
+
+The harness is model-agnostic exactly as in the reference: subclasses supply
+``create_gazeprediction_network``; the gaze_grcn subclass runs on the HIP path.  The
+fc-GRU graph of this base class (gaze_rnn.py:211-360, BASELINE config 2) has no HIP
+path yet and says so when asked to build."""
+import logging
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import evaluation_metrics
+from ..evaluation_metrics import AVAILABLE_METRICS, saliency_score
+from .base import BaseModelConfig, ModelBase, Session
+from .model_util import normalize_probability_map
+
+log = logging.getLogger('rgp')
+
+CONSTANTS = SimpleNamespace(image_width=98, image_height=98, gazemap_width=49, gazemap_height=49,
+                            saliencymap_width=49, saliencymap_height=49)        # gaze_rnn.py:34-40
+
+
+class GRUModelConfig(BaseModelConfig):
+    """gaze_rnn.py:44-61."""
+
+    def __init__(self):
+        super(GRUModelConfig, self).__init__()
+        self.n_lstm_steps = 42
+        self.batch_size = 7
+        self.dim_feature = 1024
+        self.dim_sal = 1024 * 49
+        self.dim_sal_proj = 1024
+        self.optimization_method = 'adam'
+        self.loss_type = 'xentropy'
+        self.use_flip_batch = True
+        # additions (not in the reference): MFMA operand dtype of the HIP path, weight seed
+        self.compute_dtype = 'bf16'
+        self.init_seed = 0
+
+
+class GazePredictionGRU(ModelBase):
+    """gaze_rnn.py:66-680."""
+
+    def __init__(self, session, data_sets, config=None, gazemap_height=CONSTANTS.gazemap_height,
+                 gazemap_width=CONSTANTS.gazemap_width):
+        self.session = session if session is not None else Session()
+        self.data_sets = data_sets
+        self.config = config if config is not None else GRUModelConfig()
+        super(GazePredictionGRU, self).__init__(self.config)
+        self.batch_size = self.config.batch_size
+        self.n_lstm_steps = self.config.n_lstm_steps
+        self.dim_feature = self.config.dim_feature
+        self.dim_sal = self.config.dim_sal
+        self.dim_sal_proj = self.config.dim_sal_proj
+        self.dim_cnn_proj = 32
+        self.initial_learning_rate = self.config.initial_learning_rate
+        self.learning_rate_decay = self.config.learning_rate_decay
+        self.max_grad_norm = self.config.max_grad_norm
+        self.gazemap_height, self.gazemap_width = gazemap_height, gazemap_width
+        self.image_height, self.image_width = CONSTANTS.image_height, CONSTANTS.image_width
+        self.dropout_keep_prob = 1.0
+        self.build_model()
+        self.build_train_op()
+
+    # ------------------------------------------------------------------ graph
+    def build_model(self):
+        """gaze_rnn.py:108-160: create the network (device engine) and its outputs."""
+        self.net = {}
+        self.engine = self.create_gazeprediction_network(frame_images=None, c3d_input=None,
+                                                         dropout_keep_prob=self.dropout_keep_prob, net=self.net,
+                                                         model=self)
+        self.predicted_gazemaps = None          # filled by predict(): probs for xentropy, raw maps for l2
+        self.predicted_gazemaps_logit = None
+        self.loss = None
+
+    @staticmethod
+    def create_gazeprediction_network(frame_images, c3d_input, dropout_keep_prob=1.0, net=None, model=None):
+        raise NotImplementedError('fc-GRU graph (gaze_rnn.py:211-360, config 2) has no HIP path yet; '
+                                  'use models.gaze_grcn.GazePredictionGRCN')
+
+    def build_train_op(self):
+        """gaze_rnn.py:448-478.  The backward / Adam kernels are not built yet."""
+        self.train_op = None
+
+    def learning_rate_at(self, step):
+        """_build_learning_rate (gaze_rnn.py:436-444): lr0 * decay^floor(step/500)."""
+        return self.initial_learning_rate * self._learning_rate_scale * self.learning_rate_decay ** (step // 500)
+
+    @property
+    def current_learning_rate(self):
+        return self.learning_rate_at(self.current_step)
+
+    # ------------------------------------------------------------------ execution
+    def predict(self, c3d, frames=None):
+        """Replacement for ``session.run(predicted_gazemaps, feed_dict)`` (gaze_rnn.py:603-611):
+        c3d [B,T,1024,7,7] (numpy or device tensor; frames are accepted and ignored)
+        -> numpy [B,T,GH,GW]: softmax maps for loss_type xentropy/KLD, raw maps for l2 (9-Q5)."""
+        x = torch.as_tensor(np.asarray(c3d, dtype=np.float32) if not torch.is_tensor(c3d) else c3d)
+        x = x.to(self.session.device, torch.float32).reshape(self.batch_size, self.n_lstm_steps, 1024, 7, 7).contiguous()
+        want_probs = self.config.loss_type in ('xentropy', 'KLD')
+        logits, probs = self.engine.forward(x, want_probs=want_probs)
+        self.predicted_gazemaps_logit = logits
+        self.predicted_gazemaps = probs if want_probs else logits
+        return self.predicted_gazemaps
+
+    def compute_loss(self, gt_gazemap):
+        """create_loss_and_summary (gaze_rnn.py:363-408) on the last predict()'s logits."""
+        from ..engine import softmax_xent
+        g = torch.as_tensor(np.asarray(gt_gazemap, np.float32)).to(self.session.device).contiguous()
+        z = self.predicted_gazemaps_logit
+        if self.config.loss_type == 'xentropy':
+            return float(softmax_xent(z, g.reshape(z.shape), want_probs=False)[2].item())
+        if self.config.loss_type == 'l2':
+            return float(0.5 * ((z - g.reshape(z.shape)) ** 2).sum().item() / (z.shape[0] * z.shape[1]))
+        raise NotImplementedError(str(self.config.loss_type))   # 'KLD' is broken in the reference too (:395-399)
+
+    def single_step(self, train_mode=True, dataset=None):
+        """gaze_rnn.py:483-565."""
+        _start_time = time.time()
+        if dataset is None:
+            dataset = self.data_sets.train if train_mode else self.data_sets.valid
+        if train_mode:
+            raise NotImplementedError('training step: backward/Adam HIP kernels are not built yet (DESIGN.md 7)')
+        batch_images, batch_maps, batch_fixmaps, batch_c3d, batch_pupil, batch_clipnames = dataset.next_batch(self.batch_size)
+        batch_c3d = np.reshape(batch_c3d, [self.batch_size, -1, 1024, 7, 7])
+        if self.config.loss_type in ('xentropy', 'KLD'):
+            batch_maps = normalize_probability_map(batch_maps)
+        self.predict(batch_c3d, batch_images)
+        self.loss = loss = self.compute_loss(batch_maps)
+        step = self.current_step
+        dt = time.time() - _start_time
+        log.info(" [%5s step %4d] batch total-loss: %.5f (%.3f sec/batch, %.3f instances/sec) (lr=%.3g)",
+                 'val', step, loss, dt, self.batch_size / dt, self.current_learning_rate)
+        return step
+
+    def generate(self, dataset, max_instances=50):
+        """gaze_rnn.py:568-650: same dictionary, same flattening of the time axis."""
+        GH, GW = self.gazemap_height, self.gazemap_width
+        pred_gazemap_list, gt_gazemap_list, fixationmap_list = [], [], []
+        images_list, filename_list, c3d_list = [], [], []
+        n_instances = len(dataset)
+        if max_instances is not None:
+            n_instances = min(n_instances, max_instances)
+        step_num = int(np.ceil(n_instances / float(self.batch_size)))
+        assert step_num > 0
+        for _ in range(step_num):
+            batch_images, batch_maps, batch_fixmaps, batch_c3d, batch_pupil, batch_filename = dataset.next_batch(self.batch_size)
+            batch_images = np.asarray(list(batch_images))
+            assert batch_images.dtype == np.float32
+            batch_c3d = np.reshape(batch_c3d, [self.batch_size, -1, 1024, 7, 7])
+            if self.config.loss_type == 'xentropy':
+                batch_maps = normalize_probability_map(batch_maps)
+            gazes = self.predict(batch_c3d, batch_images).cpu().numpy()
+            c3d_list.extend(batch_c3d)
+            pred_gazemap_list.extend(gazes)
+            gt_gazemap_list.extend(batch_maps)
+            fixationmap_list.extend(batch_fixmaps)
+            images_list.extend(np.concatenate(batch_images))
+            filename_list.extend(batch_filename)
+        pred_gazemap_list = np.vstack(pred_gazemap_list).reshape([-1, GH, GW])
+        gt_gazemap_list = np.vstack(gt_gazemap_list).reshape([-1, GH, GW])
+        c3d_list = np.vstack(c3d_list).reshape([-1, 1024, 7, 7])
+        try:
+            fixationmap_list = np.vstack(fixationmap_list)
+        except Exception:
+            folded = []
+            for fixationmap in fixationmap_list:
+                for t in range(len(fixationmap)):
+                    folded.append(fixationmap[t])
+            fixationmap_list = folded
+            assert len(fixationmap_list) == len(pred_gazemap_list)
+        return {'pred_gazemap_list': pred_gazemap_list, 'gt_gazemap_list': gt_gazemap_list,
+                'images_list': images_list, 'fixationmap_list': fixationmap_list,
+                'clipname_list': filename_list, 'c3d_list': c3d_list}
+
+    def evaluate(self, pred_gazemap_list, gt_gazemap_list, fixationmap_list, images_list, **_ignored):
+        """gaze_rnn.py:653-674.  Extra keys of generate()'s dictionary are accepted and ignored
+        (the reference raises TypeError there)."""
+        assert len(pred_gazemap_list) == len(gt_gazemap_list) == len(fixationmap_list) == len(images_list), \
+            "Length mismatch: %d %d %d %d" % (len(pred_gazemap_list), len(gt_gazemap_list),
+                                              len(fixationmap_list), len(images_list))
+        batch_scores = {}
+        for metric in AVAILABLE_METRICS:
+            batch_scores[metric] = saliency_score(metric, pred_gazemap_list, gt_gazemap_list, fixationmap_list)
+            log.info('Saliency %s : %f', metric, batch_scores[metric])
+        self.report_evaluate_summary(batch_scores)
+        return batch_scores
+
+    def generate_and_evaluate(self, dataset, max_instances=50):
+        ret = self.generate(dataset, max_instances)
+        return ret, self.evaluate(**ret)
+
+
+__all__ = ['CONSTANTS', 'GRUModelConfig', 'GazePredictionGRU', 'evaluation_metrics']

@@ -156,3 +156,32 @@ def fixation_maps(seed, centres, hw=49, n_fix=6, spread=3.0):
             pts = np.clip(np.round(centres[i, j] + rs.randn(n_fix, 2) * spread), 0, hw - 1).astype(int)
             out[i, j, pts[:, 0], pts[:, 1]] = 1.0
     return out
+
+
+class SyntheticDataSet(object):
+    """Stands in for crc_input_data_seq.CRCDataSet: ``len(ds)`` and ``next_batch(B)`` returning the
+    reference's 6-tuple (crc_input_data_seq.py:132-156): images [B,T,98,98,3] f32 in [0,1],
+    gazemaps [B,T,49,49] f32, fixationmaps [B,T,49,49], c3d [B,T,512,2,7,7] f32, pupils [B,T],
+    clipnames."""
+
+    def __init__(self, n_clips, n_steps, seed=0, image_hw=98):
+        self.n_clips, self.n_steps, self.seed, self.image_hw = n_clips, n_steps, seed, image_hw
+        self._cursor = 0
+
+    def __len__(self):
+        return self.n_clips
+
+    def next_batch(self, batch_size):
+        idx = [(self._cursor + i) % self.n_clips for i in range(batch_size)]
+        self._cursor = (self._cursor + batch_size) % self.n_clips
+        T = self.n_steps
+        rs = np.random.RandomState(self.seed)
+        images = rs.rand(batch_size, T, self.image_hw, self.image_hw, 3).astype(np.float32)
+        maps = np.concatenate([gaze_maps(self.seed + 17 * i + 1, 1, T)[0] for i in idx])
+        cents = np.concatenate([gaze_maps(self.seed + 17 * i + 1, 1, T)[1] for i in idx])
+        fix = fixation_maps(self.seed + 3, cents)
+        feats = np.concatenate([c3d_features(self.seed + 17 * i + 2, 1, T) for i in idx])
+        c3d = feats.reshape(batch_size, T, 512, 2, 7, 7)          # channel = c*2+d (gaze_rnn.py:494-497)
+        pupils = np.zeros((batch_size, T), np.float32)
+        names = ['synthetic_%04d' % i for i in idx]
+        return images, maps, fix, c3d, pupils, names

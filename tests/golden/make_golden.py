@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Generates the committed fixtures under tests/golden/.  Run in the BUILD container
+(``python tests/golden/make_golden.py``); the GPU box only reads the .npz files.
+
+Fixtures hold seeds + expected outputs only: inputs and weights are regenerated from
+``recurrent_gaze_prediction_amd.synthetic`` (numpy RandomState, bit-stable).
+
+* grcn_small.npz / grcn_refdims.npz / grcn_grads_small.npz / c3d_one_window.npz:
+  outputs of the float64 oracle (oracle/grcn.py direct loops, oracle/torch_ref.py
+  in float64).  The reference's model code needs TensorFlow 1.x / Python 2, absent
+  here, so these pin the ORACLE (against drift), not a running reference.
+* metrics_ref.npz: outputs of the REFERENCE's own evaluation_metrics.py
+  (/root/reference/evaluation_metrics.py), imported here with three in-memory shims
+  (SURVEY.md 8c): a ``skimage.transform.resize`` stand-in that is the identity at equal
+  shapes (the only case exercised: 49x49 maps), and ``np.bool`` / ``np.int`` aliases
+  removed in numpy >= 1.24.  AUC_shuffled is not generated: the reference's
+  implementation raises under Python 3 (evaluation_metrics.py:200-201).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import grcn, torch_ref  # noqa: E402
+from recurrent_gaze_prediction_amd import synthetic as syn  # noqa: E402
+
+REFERENCE_METRICS = '/root/reference/evaluation_metrics.py'
+
+
+def grcn_case(name, B, T, P, S, seed, use_numpy):
+    p = syn.grcn_params(seed, T, P, S, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(seed + 1, B, T)
+    gt, _ = syn.gaze_maps(seed + 2, B, T)
+    g = grcn.normalize_probability_map(gt)
+    if use_numpy:
+        logits, inter = grcn.forward(x, p, want_intermediates=True)
+        emb, hs = inter['c3d_embedded'], inter['rcn_outputs']
+        d1 = np.stack([it['d1'] for it in inter['head']], 1)
+        d2 = np.stack([it['d2'] for it in inter['head']], 1)
+    else:
+        pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+        lg, hst, embt = torch_ref.grcn_forward(torch.tensor(x, dtype=torch.float64), pt, want_hidden=True)
+        logits, hs, emb, d1, d2 = lg.numpy(), hst.numpy(), embt.numpy(), None, None
+    out = dict(config=np.array([B, T, P, S, seed]), logits=logits.astype(np.float32),
+               probs=grcn.softmax_maps(logits).astype(np.float32), loss=np.float64(grcn.loss(logits, g)),
+               loss_l2=np.float64(grcn.loss(logits, g, 'l2')),
+               h_last=hs[:, -1].astype(np.float32), emb_checksum=np.float64(np.abs(emb).sum()),
+               h_checksum=np.float64(np.abs(hs).sum()))
+    if d1 is not None:
+        out.update(d1_checksum=np.float64(np.abs(d1).sum()), d2_checksum=np.float64(np.abs(d2).sum()))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, 'loss', out['loss'], 'logit range', logits.min(), logits.max())
+
+
+def grads_case(name, B, T, P, S, seed):
+    p = syn.grcn_params(seed, T, P, S, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(seed + 1, B, T)
+    gt, _ = syn.gaze_maps(seed + 2, B, T)
+    g = grcn.normalize_probability_map(gt)
+    loss, _, grads = torch_ref.grcn_loss_and_grads(x, g, p)
+    clipped, norm = torch_ref.clip_by_global_norm(grads, 10.0)
+    pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+    m = {k: torch.zeros_like(v) for k, v in pt.items()}
+    v = {k: torch.zeros_like(v) for k, v in pt.items()}
+    lr = torch_ref.learning_rate(1e-4, 0.8, 0)
+    newp, m, v = torch_ref.adam_step_tf(pt, clipped, m, v, 0, lr)
+    out = dict(config=np.array([B, T, P, S, seed]), loss=np.float64(loss), global_norm=np.float64(norm))
+    for k, gr in grads.items():
+        out['gnorm_' + k] = np.float64(gr.norm().item())
+        if gr.numel() <= 4096:
+            out['grad_' + k] = gr.numpy().astype(np.float32)
+            out['adam1_' + k] = newp[k].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, 'loss', loss, 'global grad norm', norm)
+
+
+def c3d_case(name, seed):
+    p = syn.c3d_params(seed, scale='he')
+    v = syn.video_windows(seed + 1, 1)
+    with torch.no_grad():
+        feat, acts = torch_ref.c3d_forward(torch.tensor(v, dtype=torch.float64),
+                                           {k: torch.tensor(a, dtype=torch.float64) for k, a in p.items()}, want_all=True)
+    out = dict(config=np.array([seed]), features=feat.numpy().astype(np.float32))
+    for k, a in acts.items():
+        out['abs_sum_' + k] = np.float64(a.abs().sum().item())
+        out['zero_frac_' + k] = np.float64((a == 0).double().mean().item())
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, {k: round(float(out['zero_frac_' + k]), 3) for k in acts})
+
+
+def load_reference_metrics():
+    """Import the reference's evaluation_metrics.py with in-memory shims (see module doc)."""
+    import scipy.sparse  # noqa: F401  (before the np.int alias, as SURVEY 8c notes)
+    sk = types.ModuleType('skimage')
+    skt = types.ModuleType('skimage.transform')
+
+    def resize(img, shape, order=3, mode='constant', **kw):
+        img = np.asarray(img, dtype=np.float64)
+        assert tuple(img.shape) == tuple(shape), 'shim only supports equal shapes'
+        return img.copy()
+    skt.resize = resize
+    sk.transform = skt
+    sys.modules['skimage'] = sk
+    sys.modules['skimage.transform'] = skt
+    if not hasattr(np, 'bool'):
+        np.bool = bool
+    if not hasattr(np, 'int'):
+        np.int = int
+    spec = importlib.util.spec_from_file_location('reference_evaluation_metrics', REFERENCE_METRICS)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def metrics_case(name, seed=40, n=12):
+    ref = load_reference_metrics()
+    if not hasattr(np, 'trapz'):
+        np.trapz = np.trapezoid
+    gt, centres = syn.gaze_maps(seed, n, 1)
+    fix = syn.fixation_maps(seed + 1, centres)[:, 0]
+    gt = gt[:, 0]
+    rs = np.random.RandomState(seed + 2)
+    pred = (gt + 0.3 * rs.rand(*gt.shape) + 0.2 * np.roll(gt, 3, axis=2)).astype(np.float32)
+    out = dict(config=np.array([seed, n]))
+    sims, ccs, judd, borji = [], [], [], []
+    for i in range(n):
+        sims.append(ref.saliency_score_single('sim', pred[i], gt[i], fix[i]))
+        ccs.append(ref.saliency_score_single('cc', pred[i], gt[i], fix[i]))
+        np.random.seed(1000 + i)
+        judd.append(ref.saliency_score_single('AUC_Judd', pred[i], gt[i], fix[i]))
+        np.random.seed(2000 + i)
+        borji.append(ref.saliency_score_single('AUC_Borji', pred[i], gt[i], fix[i]))
+    out.update(sim=np.array(sims), cc=np.array(ccs), AUC_Judd=np.array(judd), AUC_Borji=np.array(borji))
+    for metric in ('sim', 'cc', 'AUC_Borji'):
+        np.random.seed(3000)
+        out['score_' + metric] = np.float64(ref.saliency_score(metric, list(pred), list(gt), list(fix)))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, {k: float(np.mean(out[k])) for k in ('sim', 'cc', 'AUC_Judd', 'AUC_Borji')})
+
+
+if __name__ == '__main__':
+    grcn_case('grcn_small.npz', 2, 3, 64, 64, 101, use_numpy=True)
+    grcn_case('grcn_refdims.npz', 1, 2, 512, 128, 111, use_numpy=False)
+    grads_case('grcn_grads_small.npz', 2, 3, 64, 64, 101)
+    c3d_case('c3d_one_window.npz', 121)
+    metrics_case('metrics_ref.npz')

@@ -1,0 +1,206 @@
+"""CPU: pins the oracle -- closed-form known answers from the cited equations, agreement of
+the two independent restatements (numpy direct loops vs torch library ops), and the
+committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import grcn, np_ops, torch_ref
+from recurrent_gaze_prediction_amd import synthetic as syn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def t64(p):
+    return {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+
+
+# ------------------------------------------------------------------ known answers
+def test_zero_weights_give_uniform_softmax_and_log_2401_loss():
+    """All-zero weights => h_t = 0, logits = out_b, softmax = 1/2401, loss = ln 2401."""
+    B, T = 2, 2
+    p = {k: np.zeros_like(v) for k, v in syn.grcn_params(1, T, 64, 64).items()}
+    p['out_b'][:] = 0.07
+    x = syn.c3d_features(2, B, T)
+    logits = grcn.forward(x, p)
+    assert np.allclose(logits, 0.07)
+    assert np.allclose(grcn.softmax_maps(logits), 1.0 / 2401)
+    gt, _ = syn.gaze_maps(3, B, T)
+    assert abs(grcn.loss(logits, grcn.normalize_probability_map(gt)) - np.log(2401.0)) < 1e-12
+
+
+def test_first_step_from_zero_state_closed_form():
+    """h_1 = (1 - sigmoid(Wz*x)) * tanh(W*x) when h_0 = 0 (gaze_grcn.py:118-127)."""
+    rs = np.random.RandomState(0)
+    p = syn.grcn_params(4, 1, 64, 64)
+    x = rs.randn(2, 7, 7, 64)
+    h1, _ = grcn.gru_rcn_cell(x, np.zeros((2, 7, 7, 64)), p)
+    expect = (1 - np_ops.sigmoid(np_ops.conv2d_same(x, p['GRU_Conv_Wz']))) * np.tanh(np_ops.conv2d_same(x, p['GRU_Conv_W']))
+    assert np.allclose(h1, expect, atol=1e-14)
+
+
+def test_update_gate_keeps_old_state():
+    """new_h = u*h + (1-u)*c: with Wz,Uz driving u -> 1 the state is carried."""
+    p = {k: np.zeros_like(v, dtype=np.float64) for k, v in syn.grcn_params(4, 1, 64, 64).items()}
+    p['GRU_Conv_Wz'][1, 1] = np.eye(64) * 50.0
+    x = np.ones((1, 7, 7, 64))
+    h = np.random.RandomState(1).randn(1, 7, 7, 64)
+    h1, g = grcn.gru_rcn_cell(x, h, p)
+    assert np.allclose(g['u'], 1.0) and np.allclose(h1, h)
+
+
+def test_batchnorm_at_init_scales_by_inv_sqrt_1p001():
+    x = np.random.RandomState(2).randn(3, 7, 7, 8)
+    y = np_ops.batchnorm_inference(x, np.ones(8), np.zeros(8))
+    assert np.allclose(y, x / np.sqrt(1.001))
+
+
+def test_deconv_sizes_and_delta_response():
+    """7 -> 23 -> 49 -> 49 (gaze_grcn.py:329,339,355); a delta input reproduces the
+    un-flipped filter at offset (3i, 3j)."""
+    rs = np.random.RandomState(3)
+    f1 = rs.randn(5, 5, 4, 6)
+    y = np.zeros((1, 7, 7, 6))
+    y[0, 2, 4, 1] = 1.0
+    out = np_ops.conv2d_transpose(y, f1, 3, 'VALID', (23, 23))
+    assert out.shape == (1, 23, 23, 4)
+    assert np.allclose(out[0, 6:11, 12:17, :], f1[:, :, :, 1])
+    assert abs(out.sum() - f1[:, :, :, 1].sum()) < 1e-12
+    f2 = rs.randn(5, 5, 3, 4)
+    assert np_ops.conv2d_transpose(out, f2, 2, 'VALID', (49, 49)).shape == (1, 49, 49, 3)
+    f3 = rs.randn(7, 7, 2, 3)
+    d = np.zeros((1, 49, 49, 3))
+    d[0, 10, 20, 2] = 1.0
+    o3 = np_ops.conv2d_transpose(d, f3, 1, 'SAME', (49, 49))
+    assert o3.shape == (1, 49, 49, 2)
+    assert np.allclose(o3[0, 7:14, 17:24, :], f3[:, :, :, 2])      # out[y,x] = in[y-a+3, x-b+3] F[a,b]
+
+
+def test_softmax_xent_matches_definition():
+    rs = np.random.RandomState(5)
+    z, g = rs.randn(4, 2401), rs.rand(4, 2401)
+    g /= g.sum(-1, keepdims=True)
+    sm = np_ops.softmax_rows(z)
+    assert np.allclose(sm.sum(-1), 1.0)
+    assert np.allclose(np_ops.softmax_xent_rows(z, g), -(g * np.log(sm)).sum(-1))
+
+
+# ------------------------------------------------------------------ two restatements agree
+@pytest.mark.parametrize('stride,pad,k,hin,hout', [(3, 'VALID', 5, 7, 23), (2, 'VALID', 5, 23, 49), (1, 'SAME', 7, 49, 49)])
+def test_conv2d_transpose_numpy_vs_torch(stride, pad, k, hin, hout):
+    rs = np.random.RandomState(6)
+    y, f = rs.randn(2, hin, hin, 5), rs.randn(k, k, 3, 5)
+    a = np_ops.conv2d_transpose(y, f, stride, pad, (hout, hout))
+    b = torch_ref.conv2d_transpose(torch.tensor(y), torch.tensor(f), stride, pad).numpy()
+    assert a.shape == b.shape and np.abs(a - b).max() < 1e-12
+
+
+def test_conv2d_same_numpy_vs_torch():
+    rs = np.random.RandomState(7)
+    x, w = rs.randn(2, 7, 7, 6), rs.randn(3, 3, 6, 4)
+    assert np.abs(np_ops.conv2d_same(x, w) - torch_ref.conv2d_same(torch.tensor(x), torch.tensor(w)).numpy()).max() < 1e-12
+
+
+def test_conv3d_and_pool_numpy_vs_torch():
+    rs = np.random.RandomState(8)
+    x, w, b = rs.randn(1, 4, 6, 6, 3), rs.randn(3, 3, 3, 3, 5), rs.randn(5)
+    a = np_ops.max_pool3d(np.maximum(np_ops.conv3d_pad1(x, w, b), 0), 2, 2)
+    xt = torch.tensor(x).permute(0, 4, 1, 2, 3)
+    bt = torch.nn.functional.max_pool3d(torch.relu(torch.nn.functional.conv3d(
+        xt, torch.tensor(w).permute(4, 3, 0, 1, 2), torch.tensor(b), padding=1)), 2)
+    assert np.abs(a - bt.permute(0, 2, 3, 4, 1).numpy()).max() < 1e-12
+
+
+def test_full_graph_numpy_vs_torch_float64():
+    B, T = 2, 2
+    p = syn.grcn_params(9, T, 64, 64, random_bn=True)
+    x = syn.c3d_features(10, B, T)
+    a = grcn.forward(x, p)
+    b = torch_ref.grcn_forward(torch.tensor(x, dtype=torch.float64), t64(p)).numpy()
+    assert np.abs(a - b).max() < 1e-13
+    gt, _ = syn.gaze_maps(11, B, T)
+    g = grcn.normalize_probability_map(gt)
+    for lt in ('xentropy', 'l2'):
+        assert abs(grcn.loss(a, g, lt) - torch_ref.gaze_loss(torch.tensor(b), torch.tensor(g), lt).item()) < 1e-12
+
+
+def test_shallownet_shapes_and_maxout():
+    """98x98 -> fc1 fan-in 3872; 112x112 -> 4608; output [N,49,49] >= 0."""
+    for hw, fan in ((98, 3872), (112, 4608)):
+        p = syn.shallownet_params(12, hw)
+        assert p['fc1_w'].shape == (fan, 4802)
+    p = {k: torch.tensor(v) for k, v in syn.shallownet_params(12, 98).items()}
+    out = torch_ref.shallownet_forward(torch.rand(2, 98, 98, 3), p)
+    assert tuple(out.shape) == (2, 49, 49) and float(out.min()) >= 0.0
+
+
+def test_tf_adam_and_clip_semantics():
+    """TF Adam: eps outside the bias correction; clip scale = clip/max(norm, clip) (9-Q9)."""
+    p = {'w': torch.tensor([1.0, -2.0], dtype=torch.float64)}
+    g = {'w': torch.tensor([30.0, 40.0], dtype=torch.float64)}
+    cg, norm = torch_ref.clip_by_global_norm(g, 10.0)
+    assert abs(norm - 50.0) < 1e-12 and torch.allclose(cg['w'], torch.tensor([6.0, 8.0], dtype=torch.float64))
+    m = {'w': torch.zeros(2, dtype=torch.float64)}
+    v = {'w': torch.zeros(2, dtype=torch.float64)}
+    newp, m, v = torch_ref.adam_step_tf(dict(p), cg, m, v, 0, 1e-3)
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    expect = p['w'] - lr_t * (0.1 * cg['w']) / (torch.sqrt(0.001 * cg['w'] ** 2) + 1e-8)
+    assert torch.allclose(newp['w'], expect, atol=1e-15)
+    assert torch_ref.learning_rate(1e-4, 0.8, 499) == 1e-4 and abs(torch_ref.learning_rate(1e-4, 0.8, 1000) - 6.4e-5) < 1e-18
+
+
+# ------------------------------------------------------------------ golden fixtures
+def _regen(gold):
+    B, T, P, S, seed = [int(v) for v in gold['config']]
+    p = syn.grcn_params(seed, T, P, S, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(seed + 1, B, T)
+    gt, _ = syn.gaze_maps(seed + 2, B, T)
+    return p, x, grcn.normalize_probability_map(gt)
+
+
+@pytest.mark.parametrize('name', ['grcn_small.npz', 'grcn_refdims.npz'])
+def test_oracle_reproduces_golden_logits(name):
+    gold = np.load(os.path.join(GOLD, name))
+    p, x, g = _regen(gold)
+    logits = torch_ref.grcn_forward(torch.tensor(x, dtype=torch.float64), t64(p)).numpy()
+    assert np.abs(logits - gold['logits']).max() < 1e-6          # fixture stored as float32
+    assert abs(grcn.loss(logits, g) - float(gold['loss'])) < 1e-9
+    assert abs(grcn.loss(logits, g, 'l2') - float(gold['loss_l2'])) < 1e-9
+
+
+def test_oracle_reproduces_golden_grads():
+    gold = np.load(os.path.join(GOLD, 'grcn_grads_small.npz'))
+    p, x, g = _regen(gold)
+    loss, _, grads = torch_ref.grcn_loss_and_grads(x, g, p)
+    assert abs(loss - float(gold['loss'])) < 1e-10
+    _, norm = torch_ref.clip_by_global_norm(grads, 10.0)
+    assert abs(norm - float(gold['global_norm'])) < 1e-10
+    for k, gr in grads.items():
+        assert abs(gr.norm().item() - float(gold['gnorm_' + k])) < 1e-9 * max(1.0, float(gold['gnorm_' + k]))
+        if 'grad_' + k in gold:
+            assert np.abs(gr.numpy() - gold['grad_' + k]).max() < 1e-7
+
+
+def test_autograd_grads_match_finite_differences():
+    """The backward oracle (autograd, float64) against central differences on a few weights."""
+    B, T, P, S = 1, 2, 64, 64
+    p = syn.grcn_params(31, T, P, S, random_bn=True)
+    x = syn.c3d_features(32, B, T)
+    gt, _ = syn.gaze_maps(33, B, T)
+    g = grcn.normalize_probability_map(gt)
+    _, _, grads = torch_ref.grcn_loss_and_grads(x, g, p)
+    rs = np.random.RandomState(34)
+    for key in ('out_W', 'weight2', 'GRU_Conv_U', 'bn_gamma', 'proj_c3d_b'):
+        idx = tuple(rs.randint(0, s) for s in p[key].shape)
+        eps = 1e-4
+        vals = []
+        for sgn in (+1, -1):
+            q = {k: v.astype(np.float64).copy() for k, v in p.items()}
+            q[key][idx] += sgn * eps
+            lg = torch_ref.grcn_forward(torch.tensor(x, dtype=torch.float64), t64(q))
+            vals.append(torch_ref.gaze_loss(lg, torch.tensor(g)).item())
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = grads[key][idx].item()
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)) + 1e-8, (key, fd, an)
