@@ -286,12 +286,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   }
   const bool b_active = (BN / 8 >= NW) || (wave < BN / 8);
 
-  auto stage = [&](int buf, int kt) {
+  // K-chunk offsets are fetched one iteration ahead of their use (a dependent load at
+  // the top of the iteration would expose a full L2 round trip before the DMA issues).
+  auto load_koff = [&](int kt) -> int {
+    kt = kt < p.nk ? kt : p.nk - 1;
+    return G == 1 ? p.koff[kt] : p.koff[kt * G + asub];
+  };
+  auto stage = [&](int buf, int kt, int koff_elems) {
     char* abuf = smem + buf * TILE_BYTES;
     char* bbuf = abuf + BM * 128;
-    long long ko;
-    if (G == 1) ko = (long long)p.koff[kt] * ESZ;
-    else ko = (long long)p.koff[kt * G + asub] * ESZ;
+    const long long ko = (long long)koff_elems * ESZ;
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + ko),
@@ -334,19 +338,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     }
   };
 
-  stage(0, 0);
+  int ko_next = load_koff(1);
+  stage(0, 0, load_koff(0));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
-  for (int kt = 0; kt < p.nk - 1; ++kt) {
-    stage(cur ^ 1, kt + 1);
+  // One loop, no peeled tail: with a separate tail the compiler rotates the accumulator
+  // registers through ~70 v_accvgpr moves per iteration.
+#pragma clang loop unroll(disable)
+  for (int kt = 0; kt < p.nk; ++kt) {
+    if (kt + 1 < p.nk) {
+      stage(cur ^ 1, kt + 1, ko_next);
+      ko_next = load_koff(kt + 2);
+    }
     compute(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
-  compute(cur);
-  __syncthreads();
 
   // ---- epilogue: one wave-row slab (WTM rows x BN cols, fp32) at a time ----
   constexpr int LDS_LD = BN + 4;

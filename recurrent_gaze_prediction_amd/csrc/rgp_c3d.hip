@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "rgp_host.h"
+#include "conv1a.hip.h"
 
 using namespace rgp;
 
@@ -42,9 +43,25 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
   return launch_igemm<T, G, P, EpiStore<T, true, true>>(p, e, s);
 }
 
+// bf16 conv1a: dedicated register-resident-filter kernel (conv1a.hip.h)
+int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s) {
+  Conv1aParams p;
+  p.in = (const bf16_t*)(c->ws + c->act_off[0]);
+  p.wp = (const bf16_t*)(c->ws + c->L[0].w_off);
+  p.bias = c->bias[0];
+  p.out = (bf16_t*)(c->ws + c->act_off[1]);
+  p.n_windows = n;
+  const long long tiles = (long long)n * C1_TILES_PER_WINDOW;
+  const int grid = (int)std::min<long long>((tiles + 3) / 4, 1024);
+  conv1a_pool_bf16_kernel<<<grid, 256, 0, s>>>(p);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 template <typename T>
 int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   constexpr int G0 = sizeof(T) == 2 ? 4 : 2;
+  if (i == 0 && sizeof(T) == 2) return run_conv1a_bf16(c, n, s);
   switch (i) {
     case 0: return run_layer<T, G0, 4>(c, i, n, s);
     case 1: case 3: case 5: return run_layer<T, 1, 8>(c, i, n, s);
@@ -138,6 +155,11 @@ int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) {
       d.tap_src = ts;
       d.pack_taps = nt * 4; d.cin_k = 4; d.cin_src = 3;
       d.s_tap = 3LL * l.cout; d.s_c = l.cout; d.s_n = 1;
+      if (dtype == RGP_BF16) {   // dedicated kernel: K = 10 (kz,ky) taps x 16, filter [64][160]
+        d.tap_src.resize(40);
+        d.pack_taps = 40;
+        d.K = C1_K;
+      }
     } else {
       for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
         tapoff.push_back(((kz * Hp + ky) * Wp + kx) * C);

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_ref
 from recurrent_gaze_prediction_amd import synthetic as syn
 from recurrent_gaze_prediction_amd.engine import GrcnEngine

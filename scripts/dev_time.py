@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recurrent_gaze_prediction_amd import synthetic as syn
 from recurrent_gaze_prediction_amd.engine import GrcnEngine, C3DEngine
 what = sys.argv[1] if len(sys.argv) > 1 else 'head'
