@@ -1,0 +1,220 @@
+// Staggered two-group implicit-GEMM kernel for the large C3D convolutions (gfx950).
+//
+// Same contraction, tables, swizzled LDS-DMA staging and LDS epilogue as igemm_kernel
+// (igemm.hip.h), but a 256x128 block tile run by 8 waves = two groups of four (waves
+// 0-3 and 4-7; waves w and w+4 share a SIMD).  Every wave alternates
+//
+//     LOAD(j):    issue its share of the LDS-DMA for K-tile j+2, read ALL of K-tile j's
+//                 fragments LDS -> registers, counted vmcnt (K-tile j+1 landed), barrier
+//     COMPUTE(j): 32 MFMAs from registers only, barrier
+//
+// and group B runs one barrier behind group A, so on every SIMD one wave is in its MFMA
+// phase while its partner is in its load phase: the matrix pipe stays busy across the
+// barrier / DMA-wait / LDS-latency that stall the simple one-barrier loop.  Three LDS
+// stages (3 x 48 KiB) keep two K-tiles of DMA in flight; waits are counted (never
+// vmcnt(0) in the steady state) and barriers are raw s_barrier, so in-flight DMA is not
+// drained (cdna_hip_programming.md "Pipelining across barriers").
+//
+// Hazards (h = half-step; A loads K-tile j at h=2j, computes at 2j+1; B one later):
+//  RAW  K-tile j is read from h=2j on.  Its DMA was issued in LOAD(j-2) (A: 2j-4, B: 2j-3)
+//       and every wave passed `vmcnt(6)` for it in LOAD(j-1) before that phase's barrier
+//       (A: end of 2j-2, B: end of 2j-1), i.e. before h=2j begins.
+//  WAR  DMA for K-tile j+2 overwrites the stage of K-tile j-1, last read in LOAD(j-1)
+//       (A: 2j-2, B: 2j-1, each followed by lgkmcnt(0) + barrier); issued at h >= 2j.
+#pragma once
+#include "igemm.hip.h"
+
+namespace rgp {
+
+struct StaggerSmem {
+  static constexpr int BM = 256, BN = 128;
+  static constexpr int STAGE_BYTES = (BM + BN) * 128;        // 48 KiB
+  static constexpr int KOFF_OFF = 3 * STAGE_BYTES;           // 144 KiB
+  static constexpr int KOFF_MAX = 256;                       // K-chunks (int each)
+  static constexpr int ROWINFO_OFF = KOFF_OFF + KOFF_MAX * 4;
+  static constexpr int BYTES = ROWINFO_OFF + BM * 16;        // 149.0 KiB
+};
+
+template <typename T, int P, class Epi>
+__global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p, const EpiParams e) {
+  constexpr int BM = StaggerSmem::BM, BN = StaggerSmem::BN, WM = 4, WN = 2;
+  constexpr int NW = 8, NT = 512;
+  constexpr int WTM = 64, WTN = 64, MI = 4, NI = 4;
+  constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8) / NW;   // 4, 2
+  constexpr int DMA_PER_TILE = A_PER_WAVE + B_PER_WAVE;                  // 6 per wave
+  constexpr int ESZ = sizeof(T);
+  constexpr int STAGE = StaggerSmem::STAGE_BYTES;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_koff = (int*)(smem + StaggerSmem::KOFF_OFF);
+  long long* s_rowin = (long long*)(smem + StaggerSmem::ROWINFO_OFF);
+  int* s_rowimg = (int*)(s_rowin + BM);
+  int* s_rowml = s_rowimg + BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool group_b = wave >= 4;
+
+  const int n_nt = (p.N + BN - 1) / BN;
+  const int n_mt = (p.M + BM - 1) / BM;
+  const int nwg = n_mt * n_nt;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, y = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  }
+  const int mt = bid / n_nt, nt = bid % n_nt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  for (int r = tid; r < BM; r += NT) {
+    int m = m0 + r;
+    const bool valid = m < p.M;
+    if (!valid) m = p.M - 1;
+    const int img = m / p.Mw, ml = m - img * p.Mw;
+    s_rowin[r] = (long long)img * p.in_img_stride + p.in_tab[ml];
+    s_rowimg[r] = valid ? img : -1;
+    s_rowml[r] = ml;
+  }
+  for (int i = tid; i < p.nk; i += NT) s_koff[i] = p.koff[i];
+  __syncthreads();
+
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const char* a_src[A_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int r = (wave * A_PER_WAVE + j) * 8 + lrow;
+    a_src[j] = (const char*)p.A + s_rowin[r] * ESZ + lchunk * 16;
+  }
+  const char* b_src[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    const int r = (wave * B_PER_WAVE + j) * 8 + lrow;
+    b_src[j] = (const char*)p.W + ((long long)(n0 + r) * p.K) * ESZ + lchunk * 16;
+  }
+
+  auto stage = [&](int st, int kt) {
+    char* abuf = smem + st * STAGE;
+    char* bbuf = abuf + BM * 128;
+    const long long ko = (long long)s_koff[kt] * ESZ;
+    const long long kb = (long long)kt * 128;
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + ko),
+                                       (__attribute__((address_space(3))) void*)(abuf + (wave * A_PER_WAVE + j) * 1024),
+                                       16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + kb),
+                                       (__attribute__((address_space(3))) void*)(bbuf + (wave * B_PER_WAVE + j) * 1024),
+                                       16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  const int a_off = (wm * WTM + frow) * 128, b_off = BM * 128 + (wn * WTN + frow) * 128;
+  const int pc0 = ((0 * 4 + fk) ^ (frow & 7)) * 16, pc1 = ((1 * 4 + fk) ^ (frow & 7)) * 16;
+
+  // ---- prologue: K-tiles 0 and 1 in flight, tile 0 landed for everybody ----
+  stage(0, 0);
+  if (p.nk > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (group_b) __builtin_amdgcn_s_barrier();      // run one half-step behind group A
+
+  int st = 0;       // stage of K-tile j
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < p.nk; ++j) {
+    // ---------------- LOAD(j) ----------------
+    const bool more = j + 2 < p.nk;
+    if (more) {
+      int st2 = st + 2;
+      if (st2 >= 3) st2 -= 3;
+      stage(st2, j + 2);
+    }
+    const char* sb = smem + st * STAGE;
+    f32x4 af[2][MI], bf[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      af[0][i] = *(const f32x4*)(sb + a_off + i * 16 * 128 + pc0);
+      af[1][i] = *(const f32x4*)(sb + a_off + i * 16 * 128 + pc1);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bf[0][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc0);
+      bf[1][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc1);
+    }
+    if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- COMPUTE(j) ----------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) Mma<T>::step(acc[i][jn], af[s][i], bf[s][jn]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    st = st + 1 == 3 ? 0 : st + 1;
+  }
+  if (!group_b) __builtin_amdgcn_s_barrier();
+  __syncthreads();
+
+  // ---- epilogue: one wave-row slab (64 rows x BN cols, fp32) at a time ----
+  constexpr int LDS_LD = BN + 4;
+  float* stg = (float*)smem;
+  constexpr int CG = BN / 8;
+  constexpr int ITEMS = (WTM / P) * CG;
+#pragma unroll 1
+  for (int slab = 0; slab < WM; ++slab) {
+    if (wm == slab) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stg[(i * 16 + fk * 4 + r) * LDS_LD + wn * WTN + jn * 16 + frow] = acc[i][jn][r];
+    }
+    __syncthreads();
+    for (int it = tid; it < ITEMS; it += NT) {
+      const int g = it / CG, cg = it - g * CG;
+      const int rt = slab * WTM + g * P;
+      const int img = s_rowimg[rt];
+      if (img >= 0) {
+        float v[8];
+        const float* src = stg + (g * P) * LDS_LD + cg * 8;
+        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+#pragma unroll
+        for (int q = 1; q < P; ++q) {
+          const f32x4 w0 = *(const f32x4*)(src + q * LDS_LD), w1 = *(const f32x4*)(src + q * LDS_LD + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], w0[i]); v1[i] = fmaxf(v1[i], w1[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+        Epi::apply(e, p.N, img, s_rowml[rt] / P, n0 + cg * 8, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace rgp

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "../../include/rgp.h"
 #include "igemm.hip.h"
 #include "kernels_misc.hip.h"
+#include "igemm_stagger.hip.h"
 
 namespace rgp {
 
@@ -134,11 +136,30 @@ int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   return RGP_OK;
 }
 
+template <typename T, int P, class Epi>
+int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
+  auto kern = igemm_stagger_kernel<T, P, Epi>;
+  constexpr int smem = StaggerSmem::BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  const int n_mt = (p.M + 255) / 256, n_nt = (p.N + 127) / 128;
+  kern<<<dim3(n_mt * n_nt), dim3(512), smem, s>>>(p, e);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 // Tile choice by output width: 128x128 (2x2 waves of 64x64) for N >= 128,
 // 128x64 (2x2 waves of 64x32) for N in (32, 64], 128x32 (4x1 waves of 32x32) below.
 template <typename T, int G, int P, class Epi>
 int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
+  static const int tile_cfg = getenv("RGP_TILE") ? atoi(getenv("RGP_TILE")) : 0;   // dev knob
+  if (G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
+    return launch_stagger<T, P, Epi>(p, e, s);
+  if (p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
   if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s);
   return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s);
