@@ -39,10 +39,10 @@ HEAD_FLOPS = {'proj': 51.38e6, 'xconv': 173.41e6, 'convgru_seq': 43.35e6, 'head'
 HEAD_FLOPS_FRAME = 432.79e6
 C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
 # kernel instantiation that executes each C3D layer (template igemm_kernel<T,BM,BN,WM,WN,G,P,Epi>)
-C3D_KERNEL_GROUP = {'conv1a': 'igemm<128x64,G4,pool4>', 'conv2a': 'igemm<128x128,G1,pool8>',
-                    'conv3b': 'igemm<128x128,G1,pool8>', 'conv4b': 'igemm<128x128,G1,pool8>',
-                    'conv3a': 'igemm<128x128,G1,pool1>', 'conv4a': 'igemm<128x128,G1,pool1>',
-                    'conv5a': 'igemm<128x128,G1,pool1>', 'conv5b': 'igemm<128x128,G1,pool1>'}
+C3D_KERNEL_GROUP = {'conv1a': 'conv1a_pool_bf16_kernel', 'conv2a': 'igemm_stagger_kernel<256x128,pool8>',
+                    'conv3b': 'igemm_stagger_kernel<256x128,pool8>', 'conv4b': 'igemm_stagger_kernel<256x128,pool8>',
+                    'conv3a': 'igemm_stagger_kernel<256x128,pool1>', 'conv4a': 'igemm_stagger_kernel<256x128,pool1>',
+                    'conv5a': 'igemm_stagger_kernel<256x128,pool1>', 'conv5b': 'igemm_stagger_kernel<256x128,pool1>'}
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
 
 
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--n-steps', type=int, default=16, help='RNN timesteps T per clip')
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
-    ap.add_argument('--c3d-chunk', type=int, default=128, help='windows per C3D launch chain')
+    ap.add_argument('--c3d-chunk', type=int, default=256, help='windows per C3D launch chain')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
     ap.add_argument('--cpu-threads', type=int, default=16, help='host threads for the CPU baseline')

@@ -74,6 +74,7 @@ struct EpiParams {
   void* out;                 // primary output
   const int* out_tab;        // [Mw/P] element offset of an output row inside one output image
   long long out_img_stride;  // elements
+  long long out_extra;       // extra element offset (box origin in conv3d_halo_kernel)
   const float* bias;         // [N]
   // ConvGRU gate epilogues (gaze_grcn.py:118-127)
   const float* xpre;         // hoisted W*x pre-activations for this step, [img][49][xpre_ld]
@@ -132,7 +133,7 @@ template <typename TO, bool BIAS, bool RELU> struct EpiStore {
       if (BIAS) v[i] += (i < nvalid) ? e.bias[n0 + i] : 0.f;
       if (RELU) v[i] = fmaxf(v[i], 0.f);
     }
-    TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_tab[ml] + n0;
+    TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
     store8<TO>(dst, v, nvalid);
   }
 };
@@ -256,6 +257,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   const int mt = bid / n_nt, nt = bid % n_nt;
   const int m0 = mt * BM, n0 = nt * BN;
 
+  // K-chunk offsets are fetched one iteration ahead of their use (a dependent load at
+  // the top of the iteration would expose a full L2 round trip before the DMA issues).
+  const int asub_ = (((tid & 7) ^ ((tid & 63) >> 3))) / (8 / G);
+  auto load_koff = [&](int kt) -> int {
+    kt = kt < p.nk ? kt : p.nk - 1;
+    return G == 1 ? p.koff[kt] : p.koff[kt * G + asub_];
+  };
+  const int ko_first = load_koff(0);   // issued before the row-table chain so the latencies overlap
+  int ko_next = load_koff(1);
+
   for (int r = tid; r < BM; r += NT) {
     int m = m0 + r;
     const bool valid = m < p.M;
@@ -286,12 +297,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   }
   const bool b_active = (BN / 8 >= NW) || (wave < BN / 8);
 
-  // K-chunk offsets are fetched one iteration ahead of their use (a dependent load at
-  // the top of the iteration would expose a full L2 round trip before the DMA issues).
-  auto load_koff = [&](int kt) -> int {
-    kt = kt < p.nk ? kt : p.nk - 1;
-    return G == 1 ? p.koff[kt] : p.koff[kt * G + asub];
-  };
   auto stage = [&](int buf, int kt, int koff_elems) {
     char* abuf = smem + buf * TILE_BYTES;
     char* bbuf = abuf + BM * 128;
@@ -338,8 +343,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     }
   };
 
-  int ko_next = load_koff(1);
-  stage(0, 0, load_koff(0));
+  stage(0, 0, ko_first);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;

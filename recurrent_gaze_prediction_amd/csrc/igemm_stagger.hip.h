@@ -35,7 +35,7 @@ struct StaggerSmem {
   static constexpr int BYTES = ROWINFO_OFF + BM * 16;        // 149.0 KiB
 };
 
-template <typename T, int P, class Epi>
+template <typename T, int P, class Epi, int ABLATE = 0>
 __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p, const EpiParams e) {
   constexpr int BM = StaggerSmem::BM, BN = StaggerSmem::BN, WM = 4, WN = 2;
   constexpr int NW = 8, NT = 512;
@@ -138,12 +138,12 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
   for (int j = 0; j < p.nk; ++j) {
     // ---------------- LOAD(j) ----------------
     const bool more = j + 2 < p.nk;
-    if (more) {
+    if (more && !(ABLATE & 2)) {
       int st2 = st + 2;
       if (st2 >= 3) st2 -= 3;
       stage(st2, j + 2);
     }
-    const char* sb = smem + st * STAGE;
+    const char* sb = smem + ((ABLATE & 4) ? 0 : st) * STAGE;
     f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       bf[0][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc0);
       bf[1][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc1);
     }
-    if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    if (more && !(ABLATE & 2)) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -167,7 +167,10 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jn = 0; jn < NI; ++jn) Mma<T>::step(acc[i][jn], af[s][i], bf[s][jn]);
+        for (int jn = 0; jn < NI; ++jn) {
+          if (ABLATE & 1) { asm volatile("" ::"v"(af[s][i]), "v"(bf[s][jn])); acc[i][jn][0] += 1.f; }
+          else Mma<T>::step(acc[i][jn], af[s][i], bf[s][jn]);
+        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

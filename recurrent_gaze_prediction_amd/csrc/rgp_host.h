@@ -136,9 +136,9 @@ int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   return RGP_OK;
 }
 
-template <typename T, int P, class Epi>
+template <typename T, int P, class Epi, int ABLATE = 0>
 int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
-  auto kern = igemm_stagger_kernel<T, P, Epi>;
+  auto kern = igemm_stagger_kernel<T, P, Epi, ABLATE>;
   constexpr int smem = StaggerSmem::BYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -156,9 +156,22 @@ int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
 template <typename T, int G, int P, class Epi>
 int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
-  static const int tile_cfg = getenv("RGP_TILE") ? atoi(getenv("RGP_TILE")) : 0;   // dev knob
+  // 2 = staggered 256x128 kernel where eligible (default, fastest measured), 0 = 128x128 only,
+  // 1 = 256x128 simple loop (dev comparison)
+  static const int tile_cfg = getenv("RGP_TILE") ? atoi(getenv("RGP_TILE")) : 2;
   if (G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
+  {
+    static const int abl = getenv("RGP_ABLATE") ? atoi(getenv("RGP_ABLATE")) : 0;
+    if (sizeof(T) == 2 && P == 8 && abl) {
+      if (abl == 1) return launch_stagger<T, P, Epi, 1>(p, e, s);
+      if (abl == 2) return launch_stagger<T, P, Epi, 2>(p, e, s);
+      if (abl == 4) return launch_stagger<T, P, Epi, 4>(p, e, s);
+      if (abl == 6) return launch_stagger<T, P, Epi, 6>(p, e, s);
+      if (abl == 3) return launch_stagger<T, P, Epi, 3>(p, e, s);
+      if (abl == 5) return launch_stagger<T, P, Epi, 5>(p, e, s);
+    }
     return launch_stagger<T, P, Epi>(p, e, s);
+  }
   if (p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
   if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s);

@@ -62,3 +62,33 @@ def test_c3d_chunking_equals_single_pass(gpu, c3d_case):
     fa, _ = a.forward(torch.tensor(v, device=gpu))
     fb, _ = b.forward(torch.tensor(v, device=gpu))
     assert torch.equal(fa, fb)
+
+
+@pytest.mark.parametrize('env', [{'RGP_TILE': '0'}, {'RGP_HALO': '1'}, {'RGP_TILE': '1'}])
+def test_alternative_conv_kernels_stay_correct(gpu, env):
+    """The 128x128 tile loop, the 256x128 simple loop and the LDS-halo direct kernel are selected by
+    environment knobs read once per process, so each runs in a child process: 8 windows (enough rows
+    for every variant's size threshold) against the default path's features, bit-for-bit where the
+    summation order is the same and within bf16 tolerance otherwise."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from recurrent_gaze_prediction_amd import synthetic as syn
+from recurrent_gaze_prediction_amd.engine import C3DEngine
+eng = C3DEngine(8, dtype='bf16'); eng.set_weights(syn.c3d_params(21))
+v = torch.tensor(syn.video_windows(23, 8), device='cuda')
+f, _ = eng.forward(v); torch.cuda.synchronize()
+np.save(sys.argv[1], f.cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = []
+    for e in ({}, env):
+        with tempfile.NamedTemporaryFile(suffix='.npy') as tf:
+            r = subprocess.run([sys.executable, '-c', code, tf.name], env=dict(os.environ, **e), capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(np.load(tf.name))
+    assert rel_err(outs[1], outs[0]) < 2e-2 and np.isfinite(outs[1]).all()
