@@ -106,6 +106,23 @@ size_t rgp_grcn_buffer_elems(const rgp_grcn_t* plan, const char* name);
 int rgp_softmax_xent_fwd(const float* logits, const float* labels, float* probs, float* frame_loss, float* loss,
                          int frames, int npix, rgp_stream_t stream);
 
+/* Backward of the same graph under the loss of gaze_rnn.py:363-408 (what tf.gradients builds,
+ * base.py:278-281).  Needs a plan created with save_for_backward=1 and a preceding
+ * rgp_grcn_forward on the same inputs (its saved states live in the workspace).
+ * logits / probs: outputs of that forward; labels: per-frame-normalised ground-truth maps
+ * [B,T,49,49] (normalize_probability_map, model_util.py:40-58).  loss_type 0 = xentropy,
+ * 1 = l2.  grads: fp32 device arrays shaped like the weights; fully overwritten. */
+int rgp_grcn_backward(rgp_grcn_t* plan, const float* logits, const float* probs, const float* labels,
+                      const rgp_grcn_weights* grads, int loss_type, rgp_stream_t stream);
+
+/* tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients on one flat fp32 parameter
+ * buffer (base.py:286-297; TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), theta -= lr_t*m/(sqrt(v)+eps),
+ * t = step+1).  workspace: 256 floats.  grad_norm_out (optional, device): the global norm.
+ * max_grad_norm <= 0 disables clipping. */
+int rgp_adam_clip_step(float* params, const float* grads, float* m, float* v, long long n, float* workspace,
+                       int step, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                       float* grad_norm_out, rgp_stream_t stream);
+
 /* Stage timing (HIP events recorded on the caller's stream around each stage launch
  * group; costs two hipEventRecord per stage).  Stages: 0 proj (incl. transpose),
  * 1 xconv, 2 convgru sequence, 3 head (transposed convs), 4 softmax.

@@ -62,6 +62,10 @@ SIGNATURES = {
     'rgp_c3d_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'rgp_c3d_read_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'rgp_c3d_layer_elems': (c_size_t, [c_void_p, c_int, c_int]),
+    'rgp_grcn_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(GrcnWeights), c_int, c_void_p]),
+    'rgp_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int,
+                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   c_void_p, c_void_p]),
     'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
     'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),

@@ -1,0 +1,326 @@
+// Backward-pass support kernels of the gaze_grcn head (gfx950): loss gradient, the
+// element-wise parts of BPTT / batch-norm, gather-transposes that turn weight gradients
+// into plain K-contiguous GEMMs for igemm_kernel, the folded 7x7 head filter's dgrad /
+// wgrad, and the fused TF-Adam + global-norm-clip optimizer.
+// What is differentiated: /root/reference/models/gaze_grcn.py:173-376 with the loss of
+// gaze_rnn.py:363-408 (tf.gradients, base.py:278-281).
+#pragma once
+#include "kernels_misc.hip.h"
+
+namespace rgp {
+
+// d loss / d logits for loss = sum_f xent_f / n_frames (gaze_rnn.py:390-407):
+//   dz = (softmax(z) * sum(g) - g) / n_frames.  One block per frame; also the frame's sum
+// of dz (for d out_b).  'l2' variant: dz = (z - g) / n_frames.
+static __global__ __launch_bounds__(256) void dlogits_kernel(const float* __restrict__ probs_or_logits,
+                                                      const float* __restrict__ labels, float* __restrict__ dz,
+                                                      float* __restrict__ frame_sum, int n, float scale, int l2) {
+  __shared__ float sh[4];
+  const long long row = blockIdx.x;
+  float gs = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) gs += labels[row * n + j];
+  gs = block_reduce(gs, sh, false);
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float p = probs_or_logits[row * n + j], g = labels[row * n + j];
+    const float d = (l2 ? (p - g) : (p * gs - g)) * scale;
+    dz[row * n + j] = d;
+    acc += d;
+  }
+  acc = block_reduce(acc, sh, false);
+  if (threadIdx.x == 0) frame_sum[row] = acc;
+}
+
+// out[0] (+)= scale * sum(x[0..n))   (single block, deterministic order)
+static __global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
+                                                  float scale) {
+  __shared__ float sh[4];
+  float a = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) a += x[i];
+  a = block_reduce(a, sh, false);
+  if (threadIdx.x == 0) *out = a * scale;
+}
+
+// Row sums of a [R][ld] matrix of T over the first n columns: out[r] = sum_m x[r][m]
+// (bias gradient from a transposed activation-gradient matrix).  One block per row.
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ x, float* __restrict__ out, long long ld,
+                                                     long long n) {
+  __shared__ float sh[4];
+  const T* r = x + (long long)blockIdx.x * ld;
+  float a = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) a += Elem<T>::from(r[i]);
+  a = block_reduce(a, sh, false);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+// Gather + transpose: dst[(row0 + tap*C + c) * ld + m] = src[base(img) + tab[tap*Mw + ml] + c]
+// (0 where tab < 0), m = img*Mw + ml, base(img) = (img % inner)*stride_inner + (img / inner)*stride_outer.
+// Turns "sum over output positions m" (weight gradients) into a K-contiguous operand.
+// Block = 64 positions x 64 channels of one tap, transposed through LDS.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void gather_transpose_kernel(const TS* __restrict__ src, TD* __restrict__ dst,
+                                                               const int* __restrict__ tab, int Mw, long long M, int C,
+                                                               long long ld, int row0, int inner,
+                                                               long long stride_inner, long long stride_outer) {
+  __shared__ float tile[64][65];
+  const int tap = blockIdx.z;
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  for (int it = threadIdx.x; it < 64 * 8; it += 256) {
+    const int r = it >> 3, cg = it & 7;
+    const long long m = m0 + r;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const long long img = m / Mw;
+      const int ml = (int)(m - img * Mw);
+      const int off = tab[tap * Mw + ml];
+      if (off >= 0) {
+        const TS* s = src + (img % inner) * stride_inner + (img / inner) * stride_outer + off + c0 + cg * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (c0 + cg * 8 + i < C) v[i] = Elem<TS>::from(s[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[r][cg * 8 + i] = v[i];
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < 64 * 8; it += 256) {
+    const int c = it >> 3, mg = it & 7;
+    if (c0 + c >= C) continue;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = tile[mg * 8 + i][c];
+    TD* d = dst + ((long long)row0 + (long long)tap * C + c0 + c) * ld + m0 + mg * 8;
+    const long long left = M - (m0 + mg * 8);
+    if (left > 0) store8<TD>(d, v, left >= 8 ? 8 : (int)left);
+  }
+}
+
+// Folded 7x7 head filter, gradient w.r.t. its input (deconv2's output):
+//   dd2[f, Y, X, c] = sum_{u,v} dz[f, Y-u, X-v] * Gp[u, v, c]   (Y,X in 0..48 un-padded coords
+//   of the 49x49 map shifted by the SAME padding 3: source pixel (Y+3-u, X+3-v) - 3 ...)
+// Precisely: logit[y,x] = sum_{u,v,c} d2pad[y+u, x+v, c] Gp[u,v,c], d2pad = d2 with halo 3, so
+//   dd2[Y,X,c] = sum_{u,v} dz[Y+3-u, X+3-v] Gp[u,v,c]  with dz = 0 outside [0,49)^2.
+// One block per (frame, row Y): 49 pixels x 32 channels, Gp (1568 floats) in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fold_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ gp,
+                                                              T* __restrict__ dd2) {
+  __shared__ float s_g[49 * 32];
+  __shared__ float s_dz[7][56];
+  const int f = blockIdx.y, Y = blockIdx.x;
+  for (int i = threadIdx.x; i < 49 * 32; i += 256) s_g[i] = gp[i];
+  for (int i = threadIdx.x; i < 7 * 56; i += 256) {
+    const int u = i / 56, xx = i % 56;            // row y = Y+3-u, column x = xx-3
+    const int y = Y + 3 - u, x = xx - 3;
+    s_dz[u][xx] = (y >= 0 && y < 49 && x >= 0 && x < 49) ? dz[((long long)f * 49 + y) * 49 + x] : 0.f;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < 49 * 4; it += 256) {
+    const int X = it >> 2, cg = it & 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 7; ++u)
+#pragma unroll
+      for (int v = 0; v < 7; ++v) {
+        const float d = s_dz[u][X + 3 - v + 3];
+        const float* g = s_g + (u * 7 + v) * 32 + cg * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += d * g[i];
+      }
+    store8<T>(dd2 + (((long long)f * 49 + Y) * 49 + X) * 32 + cg * 8, acc, 8);
+  }
+}
+
+// ... and w.r.t. the folded filter: dGp[u,v,c] += sum_{f,y,x} dz[f,y,x] * d2pad[f, y+u, x+v, c].
+// One block per (frame, output row y); partial sums over the row's 49 pixels, float atomics
+// into the 1568-entry gradient (the adds from different blocks are the only contention).
+template <typename T>
+__global__ __launch_bounds__(256) void head_fold_wgrad_kernel(const float* __restrict__ dz, const T* __restrict__ d2pad,
+                                                              float* __restrict__ dgp) {
+  __shared__ float s_dz[49];
+  const int f = blockIdx.y, y = blockIdx.x;
+  if (threadIdx.x < 49) s_dz[threadIdx.x] = dz[((long long)f * 49 + y) * 49 + threadIdx.x];
+  __syncthreads();
+  const T* img = d2pad + (long long)f * 55 * 55 * 32;
+  for (int it = threadIdx.x; it < 49 * 4; it += 256) {        // (tap, 8-channel group)
+    const int tap = it >> 2, cg = it & 3;
+    const int u = tap / 7, v = tap % 7;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const T* row = img + ((long long)(y + u) * 55 + v) * 32 + cg * 8;
+    for (int x = 0; x < 49; ++x) {
+      const float d = s_dz[x];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += d * Elem<T>::from(row[x * 32 + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(dgp + tap * 32 + cg * 8 + i, acc[i]);
+  }
+}
+
+// Un-fold: dF3[a,b,o,c] = dG[a,b,c] * out_W[o],  d out_W[o] = sum_{a,b,c} dG[a,b,c] * F3[a,b,o,c],
+// with dG[a,b,c] = dGp[6-a, 6-b, c]  (G = sum_o F3 * out_W, gaze_grcn.py:353-361).  One block.
+static __global__ __launch_bounds__(256) void head_unfold_grads_kernel(const float* __restrict__ dgp, const float* __restrict__ f3,
+                                                                const float* __restrict__ out_w, float* __restrict__ df3,
+                                                                float* __restrict__ dout_w) {
+  __shared__ float sh[4];
+  float part[12];
+#pragma unroll
+  for (int o = 0; o < 12; ++o) part[o] = 0.f;
+  for (int i = threadIdx.x; i < 49 * 32; i += 256) {
+    const int tap = i / 32, c = i % 32;
+    const int a = tap / 7, b = tap % 7;
+    const float dg = dgp[((6 - a) * 7 + (6 - b)) * 32 + c];
+#pragma unroll
+    for (int o = 0; o < 12; ++o) {
+      const long long idx = ((long long)tap * 12 + o) * 32 + c;
+      df3[idx] = dg * out_w[o];
+      part[o] += dg * f3[idx];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 12; ++o) {
+    const float r = block_reduce(part[o], sh, false);
+    if (threadIdx.x == 0) dout_w[o] = r;
+  }
+}
+
+// Batch-norm (inference form, one layer per timestep, gaze_grcn.py:325) backward:
+//   y = gamma_t * h * inv + beta_t  =>  dgamma_t[c] = inv * sum_{b,p} dy*h, dbeta_t[c] = sum dy,
+//   dh = dy * gamma_t[c] * inv.   One block per (t, 8 channels); dy rows are frame-major (b*T+t).
+static __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ hall,
+                                                     const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ dh_head, int B,
+                                                     int T_, int S, float inv) {
+  __shared__ float sh[4];
+  const int t = blockIdx.y, c0 = blockIdx.x * 8;
+  float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int rows = B * 49;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int b = r / 49, p = r % 49;
+    const float* d = dy + (((long long)b * T_ + t) * 49 + p) * S + c0;
+    const float* h = hall + (((long long)(t + 1) * B + b) * 49 + p) * S + c0;     // h_t
+    float* o = dh_head + (((long long)t * B + b) * 49 + p) * S + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sg[i] += d[i] * h[i];
+      sb[i] += d[i];
+      o[i] = d[i] * gamma[(long long)t * S + c0 + i] * inv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = block_reduce(sg[i], sh, false);
+    const float b2 = block_reduce(sb[i], sh, false);
+    if (threadIdx.x == 0) {
+      dgamma[(long long)t * S + c0 + i] = a * inv;
+      dbeta[(long long)t * S + c0 + i] = b2;
+    }
+  }
+}
+
+// BPTT step, part 1 (gaze_grcn.py:122-127 differentiated):  dh = dh_head_t + dh_carry
+//   du = dh*(h_prev - c)   dc = dh*(1-u)   dh_carry = dh*u
+//   dc_pre = dc*(1-c^2)    dz_pre = du*u*(1-u)
+// writes dXpre[:, z] and dXpre[:, c] (frame-major rows), dc_pre as a halo-padded T image
+// (operand of the U dgrad conv), and the new carry.
+template <typename T>
+__global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__ dh_head, float* __restrict__ dh_carry,
+                                                       const float* __restrict__ h_prev, const float* __restrict__ u,
+                                                       const float* __restrict__ c, float* __restrict__ dxpre,
+                                                       T* __restrict__ dcp_pad, const int* __restrict__ pad_tab, int B,
+                                                       int T_, int t, int S, int first) {
+  const long long total = (long long)B * 49 * S;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i % S);
+    const int p = (int)((i / S) % 49);
+    const int b = (int)(i / ((long long)S * 49));
+    const float dh = dh_head[i] + (first ? 0.f : dh_carry[i]);
+    const float uu = u[i], cc = c[i];
+    const float du = dh * (h_prev[i] - cc), dc = dh * (1.f - uu);
+    dh_carry[i] = dh * uu;
+    const float dcp = dc * (1.f - cc * cc), dzp = du * uu * (1.f - uu);
+    float* row = dxpre + (((long long)b * T_ + t) * 49 + p) * 3 * S;
+    row[ch] = dzp;
+    row[2 * S + ch] = dcp;
+    dcp_pad[(long long)b * 81 * S + pad_tab[p] + ch] = Elem<T>::to(dcp);
+  }
+}
+
+// BPTT step, part 2: d(r*h) from the U dgrad conv ->
+//   dr = drh*h_prev, dh_carry += drh*r, dr_pre = dr*r*(1-r); writes dXpre[:, r] and the
+//   halo-padded T image [dz_pre | dr_pre] (operand of the Uz|Ur dgrad conv).
+template <typename T>
+__global__ __launch_bounds__(256) void gru_bwd2_kernel(const float* __restrict__ drh, float* __restrict__ dh_carry,
+                                                       const float* __restrict__ h_prev, const float* __restrict__ r,
+                                                       float* __restrict__ dxpre, T* __restrict__ dzr_pad,
+                                                       const int* __restrict__ pad_tab2, int B, int T_, int t, int S) {
+  const long long total = (long long)B * 49 * S;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i % S);
+    const int p = (int)((i / S) % 49);
+    const int b = (int)(i / ((long long)S * 49));
+    const float d = drh[i], rr = r[i];
+    const float drp = d * h_prev[i] * rr * (1.f - rr);
+    dh_carry[i] += d * rr;
+    float* row = dxpre + (((long long)b * T_ + t) * 49 + p) * 3 * S;
+    row[S + ch] = drp;
+    T* img = dzr_pad + (long long)b * 81 * 2 * S + pad_tab2[p];
+    img[ch] = Elem<T>::to(row[ch]);          // dz_pre written by part 1
+    img[S + ch] = Elem<T>::to(drp);
+  }
+}
+
+// rh[t] = r[t] * h[t]  (h[t] = h_{t-1} of step t; both [T][B][49][S] fp32)
+static __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+
+// fp32 [rows][C] -> halo-padded T image [rows/49][81][C]
+template <typename T>
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                       const int* __restrict__ pad_tab, long long total, int C) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int p = (int)((i / C) % 49);
+    const long long f = i / ((long long)C * 49);
+    dst[f * 81 * C + pad_tab[p] + c] = Elem<T>::to(src[i]);
+  }
+}
+
+// ---- optimizer (base.py:262-308; TF semantics) ------------------------------
+// partial[b] = sum of squares of block b's grid-stride share (deterministic two-stage norm)
+static __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long n,
+                                                             float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float a = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) a += g[i] * g[i];
+  a = block_reduce(a, sh, false);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+// clip_by_global_norm + AdamOptimizer.apply_gradients:
+//   scale = clip / max(norm, clip);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   theta -= lr_t * m / (sqrt(v) + eps),  lr_t = lr * sqrt(1-b2^t) / (1-b1^t)  (passed in).
+static __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n,
+                                                        const float* __restrict__ sq_partial, int n_partial, float clip,
+                                                        float lr_t, float b1, float b2, float eps,
+                                                        float* __restrict__ norm_out) {
+  float sq = 0.f;
+  for (int i = 0; i < n_partial; ++i) sq += sq_partial[i];     // same order in every thread
+  const float norm = sqrtf(sq);
+  const float scale = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace rgp

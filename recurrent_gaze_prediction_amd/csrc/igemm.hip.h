@@ -138,6 +138,26 @@ template <typename TO, bool BIAS, bool RELU> struct EpiStore {
   }
 };
 
+// out (fp32) += acc : the second contribution to the carried state gradient in BPTT.
+struct EpiAccumF32 {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    const int nvalid = N - n0;
+    if (nvalid <= 0) return;
+    float* dst = (float*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
+    for (int i = 0; i < 8 && i < nvalid; ++i) dst[i] += v[i];
+  }
+};
+
+// out (fp32) += acc with global float atomics: split-K partial sums of the wgrad GEMMs.
+struct EpiAtomicAddF32 {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    const int nvalid = N - n0;
+    if (nvalid <= 0) return;
+    float* dst = (float*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
+    for (int i = 0; i < 8 && i < nvalid; ++i) atomicAdd(dst + i, v[i]);
+  }
+};
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   const float e = expf(-2.f * fabsf(x));
@@ -264,8 +284,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     kt = kt < p.nk ? kt : p.nk - 1;
     return G == 1 ? p.koff[kt] : p.koff[kt * G + asub_];
   };
-  const int ko_first = load_koff(0);   // issued before the row-table chain so the latencies overlap
-  int ko_next = load_koff(1);
+  // split-K (gridDim.y > 1, wgrad GEMMs): this block reduces K-chunks [kt_begin, kt_end)
+  const int kt_begin = (int)((long long)p.nk * blockIdx.y / gridDim.y);
+  const int kt_end = (int)((long long)p.nk * (blockIdx.y + 1) / gridDim.y);
+  const int ko_first = load_koff(kt_begin);   // issued before the row-table chain so the latencies overlap
+  int ko_next = load_koff(kt_begin + 1);
 
   for (int r = tid; r < BM; r += NT) {
     int m = m0 + r;
@@ -343,15 +366,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     }
   };
 
-  stage(0, 0, ko_first);
+  stage(0, kt_begin, ko_first);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
   // One loop, no peeled tail: with a separate tail the compiler rotates the accumulator
   // registers through ~70 v_accvgpr moves per iteration.
 #pragma clang loop unroll(disable)
-  for (int kt = 0; kt < p.nk; ++kt) {
-    if (kt + 1 < p.nk) {
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) {
       stage(cur ^ 1, kt + 1, ko_next);
       ko_next = load_koff(kt + 2);
     }

@@ -25,24 +25,28 @@ __global__ __launch_bounds__(256) void nchw_to_rows_kernel(const float* __restri
   }
 }
 
-// Generic filter packer: dst[(row0+n)*K + tap*cin_k + c] =
-//   src[tap_src[tap]*s_tap + n*s_n + c*s_c]   (0 if tap_src<0 or c>=cin_src).
+// Generic filter packer: dst[(row0+n)*K + tap*cin_k + k0 + c] =
+//   src[tap_src[tap]*s_tap + n*s_n + c*s_c]   (0 if tap_src<0).
+// grouped == 0: every c in [0, cin_k) is written (0 for c >= cin_src: channel padding).
+// grouped != 0: several source filters share the packed K axis of one tap (gate-concatenated
+//   dgrad filters); only c in [0, cin_src) is written, at column offset k0.
 // Covers HWIO/DHWIO conv filters, the [kh,kw,out,in] transposed-conv filters per
 // sub-pixel phase, 180-degree rotated filters for dgrad, and channel padding.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                           const int* __restrict__ tap_src, int ntaps, int cin_k,
                                                           int cin_src, int n_rows, int row0, int K, long long s_tap,
-                                                          long long s_n, long long s_c) {
+                                                          long long s_n, long long s_c, int k0, int grouped) {
   const long long total = (long long)n_rows * ntaps * cin_k;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % cin_k);
     const int tap = (int)((i / cin_k) % ntaps);
     const int n = (int)(i / ((long long)cin_k * ntaps));
+    if (grouped && c >= cin_src) continue;
     const int ts = tap_src ? tap_src[tap] : tap;
     float v = 0.f;
     if (ts >= 0 && c < cin_src) v = src[ts * s_tap + n * s_n + c * s_c];
-    dst[(long long)(row0 + n) * K + tap * cin_k + c] = Elem<T>::to(v);
+    dst[(long long)(row0 + n) * K + tap * cin_k + k0 + c] = Elem<T>::to(v);
   }
 }
 

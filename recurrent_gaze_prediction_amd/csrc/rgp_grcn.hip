@@ -4,37 +4,11 @@
 #include <algorithm>
 #include <map>
 
-#include "rgp_host.h"
+#include "rgp_grcn_plan.h"
 
 using namespace rgp;
 
-struct Buf {
-  size_t off = 0, bytes = 0;
-};
-
-struct rgp_grcn {
-  int B = 0, T = 0, P = 0, S = 0, dtype = RGP_BF16, save = 0, F = 0;
-  ConvDesc proj, proj_rows, xconv, gzr, gc, d3;
-  std::vector<ConvDesc> d1, d2;
-  // read_buffer tables (host copies + offsets)
-  std::vector<int> tab_pad9_P, tab_pad9_S, tab_pad27, tab_pad55, tab_lin49_3S, tab_lin49_S;
-  size_t o_pad9_P = 0, o_pad9_S = 0, o_pad27 = 0, o_pad55 = 0, o_lin49_3S = 0, o_lin49_S = 0;
-  Buf xt, E, xpre, hall, uall, rall, call, hp, rhp, hbn, D1, D2, gfold, frame_loss;
-  size_t ws_bytes = 0;
-  char* ws = nullptr;
-  bool weights_set = false;
-  const float *bn_gamma = nullptr, *bn_beta = nullptr, *proj_b = nullptr, *out_b = nullptr;
-  StageProfiler prof;
-};
-
 namespace {
-
-Buf take(Arena& a, size_t bytes) {
-  Buf b;
-  b.bytes = bytes;
-  b.off = a.take(bytes);
-  return b;
-}
 
 // Gather-form sub-pixel phases of tf.nn.conv2d_transpose(VALID, stride s, k x k,
 // filter [k,k,Cout,Cin]) (gaze_grcn.py:326-343):
@@ -311,12 +285,17 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es);
   g->gfold = take(a, 50 * 32 * 4);
   g->frame_loss = take(a, (size_t)F * 4);
+  if (g->save) {
+    const int rc = grcn_bwd_plan(g, a);
+    if (rc != RGP_OK) { delete g; return rc; }
+  }
   g->ws_bytes = a.off;
   *plan = g;
   return RGP_OK;
 }
 
 int rgp_grcn_destroy(rgp_grcn_t* plan) {
+  if (plan) grcn_bwd_destroy(plan);
   delete plan;
   return RGP_OK;
 }
@@ -343,6 +322,7 @@ int rgp_grcn_bind_workspace(rgp_grcn_t* g, void* workspace, size_t bytes, rgp_st
   RGP_TRY(up(g->tab_pad9_P, g->o_pad9_P)); RGP_TRY(up(g->tab_pad9_S, g->o_pad9_S));
   RGP_TRY(up(g->tab_pad27, g->o_pad27)); RGP_TRY(up(g->tab_pad55, g->o_pad55));
   RGP_TRY(up(g->tab_lin49_3S, g->o_lin49_3S)); RGP_TRY(up(g->tab_lin49_S, g->o_lin49_S));
+  if (g->save) RGP_TRY(grcn_bwd_upload(g, s));
   return RGP_OK;
 }
 
@@ -353,7 +333,9 @@ int rgp_grcn_set_weights(rgp_grcn_t* g, const rgp_grcn_weights* w, rgp_stream_t 
   for (size_t i = 0; i < sizeof(rgp_grcn_weights) / sizeof(float*); ++i)
     RGP_REQUIRE(ptrs[i], "rgp_grcn_set_weights: weight pointer %zu is null", i);
   hipStream_t s = (hipStream_t)stream;
-  return g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s) : set_weights_impl<float>(g, w, s);
+  RGP_TRY(g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s) : set_weights_impl<float>(g, w, s));
+  if (g->save) RGP_TRY(grcn_bwd_pack(g, w, s));
+  return RGP_OK;
 }
 
 int rgp_proj_fwd(rgp_grcn_t* g, const float* c3d_input, rgp_stream_t stream) {

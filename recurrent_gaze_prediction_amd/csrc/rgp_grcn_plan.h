@@ -1,0 +1,38 @@
+// Plan object of the gaze_grcn path, shared by the forward (rgp_grcn.hip) and backward
+// (rgp_grcn_bwd.hip) translation units.
+#pragma once
+#include "rgp_host.h"
+
+struct Buf {
+  size_t off = 0, bytes = 0;
+};
+
+struct rgp_grcn {
+  int B = 0, T = 0, P = 0, S = 0, dtype = RGP_BF16, save = 0, F = 0;
+  rgp::ConvDesc proj, proj_rows, xconv, gzr, gc, d3;
+  std::vector<rgp::ConvDesc> d1, d2;
+  // read_buffer tables (host copies + offsets)
+  std::vector<int> tab_pad9_P, tab_pad9_S, tab_pad27, tab_pad55, tab_lin49_3S, tab_lin49_S;
+  size_t o_pad9_P = 0, o_pad9_S = 0, o_pad27 = 0, o_pad55 = 0, o_lin49_3S = 0, o_lin49_S = 0;
+  Buf xt, E, xpre, hall, uall, rall, call, hp, rhp, hbn, D1, D2, gfold, frame_loss;
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  bool weights_set = false;
+  const float *bn_gamma = nullptr, *bn_beta = nullptr, *proj_b = nullptr, *out_b = nullptr;
+  rgp::StageProfiler prof;
+  struct GrcnBwd* bwd = nullptr;   // backward plan (save_for_backward only), rgp_grcn_bwd.hip
+};
+
+
+inline Buf take(rgp::Arena& a, size_t bytes) {
+  Buf b;
+  b.bytes = bytes;
+  b.off = a.take(bytes);
+  return b;
+}
+
+// rgp_grcn_bwd.hip
+int grcn_bwd_plan(rgp_grcn* g, rgp::Arena& a);
+int grcn_bwd_upload(rgp_grcn* g, hipStream_t s);
+int grcn_bwd_pack(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s);
+void grcn_bwd_destroy(rgp_grcn* g);

@@ -111,18 +111,21 @@ inline bool build_k_schedule(ConvDesc& d, const std::vector<int>& tapoff, const 
 int upload_desc(const ConvDesc& d, char* ws, hipStream_t s);
 
 template <typename T>
-int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int row0, hipStream_t s) {
+int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int row0, hipStream_t s, int k0 = 0,
+                int grouped = 0) {
+  // grouped != 0: the packed K axis holds several source filters side by side per tap (column
+  // offset k0, cin_src channels each); the buffer is pre-zeroed, padding is never written.
   const long long total = (long long)n_rows * d.pack_taps * d.cin_k;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   pack_filter_kernel<T><<<blocks, 256, 0, s>>>(src, (T*)(ws + d.w_off), (const int*)(ws + d.tap_src_off), d.pack_taps,
-                                               d.cin_k, d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_n, d.s_c);
+                                               d.cin_k, d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_n, d.s_c, k0, grouped);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
 
 // ---- launch dispatch -------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
-int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
+int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
   auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi>;
   constexpr int smem = IgemmSmem<BM, BN>::BYTES;
   static bool attr_done = false;
@@ -131,7 +134,7 @@ int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
     attr_done = true;
   }
   const int n_mt = (p.M + BM - 1) / BM, n_nt = (p.N + BN - 1) / BN;
-  kern<<<dim3(n_mt * n_nt), dim3(WM * WN * 64), smem, s>>>(p, e);
+  kern<<<dim3(n_mt * n_nt, ksplit), dim3(WM * WN * 64), smem, s>>>(p, e);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
@@ -154,12 +157,12 @@ int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
 // Tile choice by output width: 128x128 (2x2 waves of 64x64) for N >= 128,
 // 128x64 (2x2 waves of 64x32) for N in (32, 64], 128x32 (4x1 waves of 32x32) below.
 template <typename T, int G, int P, class Epi>
-int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
+int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
   if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
   // 2 = staggered 256x128 kernel where eligible (default, fastest measured), 0 = 128x128 only,
   // 1 = 256x128 simple loop (dev comparison)
   static const int tile_cfg = getenv("RGP_TILE") ? atoi(getenv("RGP_TILE")) : 2;
-  if (G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
+  if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
   {
     static const int abl = getenv("RGP_ABLATE") ? atoi(getenv("RGP_ABLATE")) : 0;
     if (sizeof(T) == 2 && P == 8 && abl) {
@@ -172,10 +175,10 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
     }
     return launch_stagger<T, P, Epi>(p, e, s);
   }
-  if (p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
-  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s);
-  if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s);
-  return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s);
+  if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
+  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s, ksplit);
+  if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
+  return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s, ksplit);
 }
 
 inline IgemmParams make_params(const ConvDesc& d, const void* A, char* ws, int n_img) {

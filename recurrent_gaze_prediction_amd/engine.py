@@ -63,16 +63,68 @@ class GrcnEngine(object):
         if h:
             self.lib.rgp_grcn_destroy(h)
 
-    def set_weights(self, params):
-        """params: dict keyed by the reference's TF variable names -> array/tensor (fp32)."""
-        w = {k: _as_dev_f32(params[k], self.device) for k in GRCN_PARAM_TO_FIELD}
-        assert tuple(w['bn_gamma'].shape) == (self.T, self.S), 'one batch-norm layer per timestep (SURVEY 9-Q1)'
+    def _flat_views(self, like):
+        """One flat fp32 buffer + per-variable views (one all-reduce bucket, one Adam launch)."""
+        sizes = [(k, tuple(like[k].shape)) for k in GRCN_PARAM_TO_FIELD]
+        flat = torch.zeros(sum(int(np.prod(s)) for _, s in sizes), dtype=torch.float32, device=self.device)
+        views, off = {}, 0
+        for k, shp in sizes:
+            n = int(np.prod(shp))
+            views[k] = flat[off:off + n].view(shp)
+            off += n
+        return flat, views
+
+    def _struct(self, views):
         st = _lib.GrcnWeights()
         for k, f in GRCN_PARAM_TO_FIELD.items():
-            setattr(st, f, w[k].data_ptr())
-        self.weights = w                    # keep alive: the plan holds raw pointers to biases / BN
+            setattr(st, f, views[k].data_ptr())
+        return st
+
+    def set_weights(self, params):
+        """params: dict keyed by the reference's TF variable names -> array/tensor (fp32).
+        The values are copied into the engine's flat fp32 master buffer."""
+        src = {k: _as_dev_f32(params[k], self.device) for k in GRCN_PARAM_TO_FIELD}
+        assert tuple(src['bn_gamma'].shape) == (self.T, self.S), 'one batch-norm layer per timestep (SURVEY 9-Q1)'
+        if self.weights is None:
+            self.flat_params, self.weights = self._flat_views(src)
+        for k in GRCN_PARAM_TO_FIELD:
+            self.weights[k].copy_(src[k])
+        self.repack()
+
+    def repack(self):
+        """Re-pack the master weights into MFMA operand form (after set_weights / an optimizer step)."""
+        st = self._struct(self.weights)     # the plan keeps raw pointers to biases / BN: views stay alive
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_grcn_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def backward(self, logits, probs, labels, loss_type='xentropy'):
+        """Gradients of the reference loss (gaze_rnn.py:363-408) w.r.t. every variable, after a
+        forward() on the same inputs.  labels: normalised gt maps [B,T,49,49] fp32 device tensor.
+        Returns {TF variable name: fp32 gradient view}; the flat buffer is self.flat_grads."""
+        assert labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous()
+        if getattr(self, 'grads', None) is None:
+            self.flat_grads, self.grads = self._flat_views(self.weights)
+        st = self._struct(self.grads)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_backward(self._h, _ptr(logits), _ptr(probs), _ptr(labels), ctypes.byref(st),
+                                                  {'xentropy': 0, 'l2': 1}[loss_type], _stream_ptr(self.device)))
+        return self.grads
+
+    def adam_step(self, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """clip_by_global_norm + TF AdamOptimizer on the flat buffers (base.py:286-297), then repack.
+        Returns a 1-element device tensor holding the pre-clip global gradient norm."""
+        if getattr(self, 'adam_m', None) is None:
+            self.adam_m = torch.zeros_like(self.flat_params)
+            self.adam_v = torch.zeros_like(self.flat_params)
+            self._opt_ws = torch.zeros(256, dtype=torch.float32, device=self.device)
+            self._gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_adam_clip_step(_ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.adam_m),
+                                                   _ptr(self.adam_v), self.flat_params.numel(), _ptr(self._opt_ws),
+                                                   int(step), float(lr), beta1, beta2, eps, float(max_grad_norm),
+                                                   _ptr(self._gnorm), _stream_ptr(self.device)))
+        self.repack()
+        return self._gnorm
 
     def forward(self, c3d_input, want_probs=True, out_logits=None, out_probs=None):
         """c3d_input [B,T,1024,7,7] fp32 device tensor -> (logits, probs) [B,T,49,49]."""
