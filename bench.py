@@ -51,7 +51,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['e2e', 'head'], default='e2e')
+    ap.add_argument('--workload', choices=['e2e', 'head', 'train'], default='e2e',
+                    help="train = head training step on precomputed features (BASELINE config 4: fwd + bwd + "
+                         "gradient all-reduce + clipped Adam; pass --batch 8 --n-steps 35 for its shape)")
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--n-steps', type=int, default=16, help='RNN timesteps T per clip')
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
@@ -110,7 +112,7 @@ def main():
     dist = rdist.init(backend='nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
     B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
 
-    head = GrcnEngine(B, T, dtype=args.dtype, device=dev)
+    head = GrcnEngine(B, T, dtype=args.dtype, save_for_backward=args.workload == 'train', device=dev)
     head.set_weights(syn.grcn_params(1, T))
     logits = torch.empty(B, T, 49, 49, device=dev)
     probs = torch.empty_like(logits)
@@ -125,12 +127,25 @@ def main():
         def step():
             c3d.forward(video, want_features=False, want_rows=True, out_rows=rows)
             head.forward_rows(rows, out_logits=logits, out_probs=probs)
-    else:
+    elif args.workload == 'head':
         c3d = None
         x = torch.relu(torch.randn(B, T, 1024, 7, 7, device=dev, generator=g))    # conv5b is post-ReLU
 
         def step():
             head.forward(x, out_logits=logits, out_probs=probs)
+    else:
+        c3d = None
+        x = torch.relu(torch.randn(B, T, 1024, 7, 7, device=dev, generator=g))
+        gt = torch.rand(B, T, 49, 49, device=dev, generator=g) + 1e-3
+        gt = (gt / gt.sum((-1, -2), keepdim=True)).contiguous()
+        counter = [0]
+
+        def step():
+            head.forward(x, out_logits=logits, out_probs=probs)
+            head.backward(logits, probs, gt)
+            rdist.allreduce_mean_(dist, [head.flat_grads])        # RCCL, before the global-norm clip
+            head.adam_step(counter[0], 1e-4 * 0.8 ** (counter[0] // 500), max_grad_norm=10.0)
+            counter[0] += 1
 
     def barrier():
         rdist.barrier(dist, dev)
@@ -182,15 +197,20 @@ def main():
             'config': {'workload': ('gaze_grcn end-to-end: synthetic 16x112x112x3 windows -> C3D conv1a-5b -> '
                                     '1024->512 proj -> ConvGRU(512->128, 7x7) -> deconv head -> 49x49 softmax maps'
                                     if c3d is not None else
-                                    'gaze_grcn head on precomputed C3D conv5b features [B,T,1024,7,7]'),
+                                    'gaze_grcn head on precomputed C3D conv5b features [B,T,1024,7,7]'
+                                    if args.workload == 'head' else
+                                    'gaze_grcn TRAINING step on precomputed features: forward + backward + gradient '
+                                    'all-reduce (mean, before the clip) + clip_by_global_norm(10) + TF-Adam'),
                        'clips_per_gpu': B, 'n_lstm_steps': T, 'frames_per_step_per_gpu': F,
-                       'parallelism': 'dp%d (clip-sharded replicas, no collective)' % world,
+                       'parallelism': ('dp%d (clip-sharded, one flat RCCL all-reduce of the 12 MB gradient per step)' % world
+                                       if args.workload == 'train' else
+                                       'dp%d (clip-sharded replicas, no collective)' % world),
                        'weights': 'random init (reference initialisers), GRU filters std 0.05'},
             'algorithmic_tflops': round(value * flops_frame / 1e12, 2),
             'stage_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in list(cprof.items()) + list(hprof.items())},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != 'train':
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
         print(json.dumps(out))

@@ -57,7 +57,7 @@ class GazePredictionGRCN(GazePredictionGRU):
         B, T = model.batch_size, model.n_lstm_steps
         P, S = GazePredictionGRCN.DIM_CNN_PROJ, GazePredictionGRCN.RNN_STATE_SIZE
         engine = GrcnEngine(B, T, P, S, dtype=getattr(model.config, 'compute_dtype', 'bf16'),
-                            device=model.session.device)
+                            save_for_backward=getattr(model.config, 'trainable', True), device=model.session.device)
         # reference initialisers (gaze_grcn.py:64-81,234-237,292-314); BN gamma=1, beta=0 per step
         model.variables = synthetic.grcn_params(getattr(model.config, 'init_seed', 0), T, P, S, gru_std=1e-4)
         engine.set_weights(model.variables)
@@ -66,7 +66,8 @@ class GazePredictionGRCN(GazePredictionGRU):
 
     # ---- variables (TF names), for checkpoints and for loading exported weights ----------
     def state_dict(self):
-        return {k: np.array(v, copy=True) for k, v in self.variables.items()}
+        # the engine's fp32 master weights are the live variables (updated by the optimizer)
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.engine.weights.items()}
 
     def load_state_dict(self, state):
         missing = [k for k in GRCN_PARAM_TO_FIELD if k not in state]

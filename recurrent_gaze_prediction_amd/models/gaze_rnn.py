@@ -82,8 +82,26 @@ class GazePredictionGRU(ModelBase):
                                   'use models.gaze_grcn.GazePredictionGRCN')
 
     def build_train_op(self):
-        """gaze_rnn.py:448-478.  The backward / Adam kernels are not built yet."""
-        self.train_op = None
+        """gaze_rnn.py:448-478 + base.py:262-308: gradients of the loss w.r.t. every non-ShallowNet
+        variable, clip_by_global_norm(max_grad_norm), AdamOptimizer(lr schedule).  Here: the engine's
+        backward + fused Adam kernels; with WORLD_SIZE > 1 the flat gradient bucket is all-reduced
+        (mean) over RCCL before the clip, so the clip sees the global-batch gradient."""
+        assert self.config.optimization_method == 'adam', 'only the reference default (adam) has a HIP kernel'
+        self.dist = None           # set by attach_process_group()
+        self.train_op = self._train_op
+
+    def attach_process_group(self, dist):
+        """dist: torch.distributed (already initialised, backend nccl = RCCL) or None."""
+        self.dist = dist
+
+    def _train_op(self, logits, probs, labels_dev):
+        from .. import dist as rdist
+        self.engine.backward(logits, probs, labels_dev, 'l2' if self.config.loss_type == 'l2' else 'xentropy')
+        if self.dist is not None:
+            rdist.allreduce_mean_(self.dist, [self.engine.flat_grads])
+        self.grad_norm = self.engine.adam_step(self._global_step, self.learning_rate_at(self._global_step),
+                                               max_grad_norm=self.max_grad_norm)
+        self._global_step += 1
 
     def learning_rate_at(self, step):
         """_build_learning_rate (gaze_rnn.py:436-444): lr0 * decay^floor(step/500)."""
@@ -122,18 +140,31 @@ class GazePredictionGRU(ModelBase):
         _start_time = time.time()
         if dataset is None:
             dataset = self.data_sets.train if train_mode else self.data_sets.valid
-        if train_mode:
-            raise NotImplementedError('training step: backward/Adam HIP kernels are not built yet (DESIGN.md 7)')
         batch_images, batch_maps, batch_fixmaps, batch_c3d, batch_pupil, batch_clipnames = dataset.next_batch(self.batch_size)
         batch_c3d = np.reshape(batch_c3d, [self.batch_size, -1, 1024, 7, 7])
         if self.config.loss_type in ('xentropy', 'KLD'):
             batch_maps = normalize_probability_map(batch_maps)
+        if train_mode and self.config.use_flip_batch:
+            # gaze_rnn.py:504-510: mirror a random half of the clips left-right (global numpy RNG;
+            # Python-2 integer division)
+            batch_images, batch_maps, batch_c3d = np.array(batch_images), np.array(batch_maps), np.array(batch_c3d)
+            indices = np.random.choice(self.batch_size, self.batch_size // 2, replace=False)
+            batch_images[indices] = batch_images[indices][:, :, :, ::-1, :]
+            batch_maps[indices] = batch_maps[indices][:, :, :, ::-1]
+            batch_c3d[indices] = batch_c3d[indices][:, :, :, :, ::-1]
+            if isinstance(batch_fixmaps, np.ndarray) and batch_fixmaps.dtype != object:
+                batch_fixmaps = np.array(batch_fixmaps)
+                batch_fixmaps[indices] = batch_fixmaps[indices][:, :, :, ::-1]
         self.predict(batch_c3d, batch_images)
         self.loss = loss = self.compute_loss(batch_maps)
+        if train_mode:
+            labels = torch.as_tensor(np.ascontiguousarray(batch_maps, np.float32)).to(self.session.device)
+            self.train_op(self.predicted_gazemaps_logit, self.predicted_gazemaps, labels.reshape(self.predicted_gazemaps_logit.shape).contiguous())
         step = self.current_step
         dt = time.time() - _start_time
-        log.info(" [%5s step %4d] batch total-loss: %.5f (%.3f sec/batch, %.3f instances/sec) (lr=%.3g)",
-                 'val', step, loss, dt, self.batch_size / dt, self.current_learning_rate)
+        if (not train_mode) or step % max(1, self.config.steps_per_logprint) == 0:
+            log.info(" [%5s step %4d] batch total-loss: %.5f (%.3f sec/batch, %.3f instances/sec) (lr=%.3g)",
+                     'train' if train_mode else 'val', step, loss, dt, self.batch_size / dt, self.current_learning_rate)
         return step
 
     def generate(self, dataset, max_instances=50):
