@@ -132,6 +132,28 @@ int rgp_adam_clip_step(float* params, const float* grads, float* m, float* v, lo
 int rgp_grcn_profile_enable(rgp_grcn_t* plan, int enable);
 int rgp_grcn_profile_read(rgp_grcn_t* plan, double ms[RGP_GRCN_STAGES], long long calls[RGP_GRCN_STAGES]);
 
+/* ------------------------------------------------------------------ fc-GRU (gaze_rnn) */
+typedef struct rgp_fcgru rgp_fcgru_t;
+
+/* GazePredictionGRU.create_gazeprediction_network (models/gaze_rnn.py:211-360), fp32 device
+ * pointers: proj_c3d_W [1024,32] proj_c3d_b [32] (gaze_rnn.py:294-295); TF-1.x GRUCell(1617)
+ * variables gates_kernel [1568+1617, 2*1617] (columns [r | u]), gates_bias [2*1617],
+ * candidate_kernel [1568+1617, 1617], candidate_bias [1617] (gaze_rnn.py:315);
+ * proj_out_W [1617, GH*GW], proj_out_b [GH*GW] (gaze_rnn.py:319-320). */
+typedef struct rgp_fcgru_weights {
+  const float *proj_c3d_W, *proj_c3d_b;
+  const float *gates_kernel, *gates_bias, *candidate_kernel, *candidate_bias;
+  const float *proj_out_W, *proj_out_b;
+} rgp_fcgru_weights;
+
+int rgp_fcgru_create(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_h, int gazemap_w, int dtype);
+int rgp_fcgru_destroy(rgp_fcgru_t* plan);
+size_t rgp_fcgru_workspace_bytes(const rgp_fcgru_t* plan);
+int rgp_fcgru_bind_workspace(rgp_fcgru_t* plan, void* workspace, size_t bytes, rgp_stream_t stream);
+int rgp_fcgru_set_weights(rgp_fcgru_t* plan, const rgp_fcgru_weights* w, rgp_stream_t stream);
+/* c3d_input [B,T,1024,7,7] -> logits [B,T,GH,GW]; probs (optional) = per-frame softmax. */
+int rgp_fcgru_forward(rgp_fcgru_t* plan, const float* c3d_input, float* logits, float* probs, rgp_stream_t stream);
+
 /* ------------------------------------------------------------------ C3D conv stack */
 typedef struct rgp_c3d rgp_c3d_t;
 

@@ -31,6 +31,12 @@ class GrcnWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in FIELDS]
 
 
+class FcGruWeights(ctypes.Structure):
+    FIELDS = ('proj_c3d_W', 'proj_c3d_b', 'gates_kernel', 'gates_bias', 'candidate_kernel', 'candidate_bias',
+              'proj_out_W', 'proj_out_b')
+    _fields_ = [(n, c_void_p) for n in FIELDS]
+
+
 class C3DWeights(ctypes.Structure):
     _fields_ = [('w', c_void_p * 8), ('b', c_void_p * 8)]
 
@@ -54,6 +60,12 @@ SIGNATURES = {
     'rgp_grcn_read_buffer': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
     'rgp_grcn_buffer_elems': (c_size_t, [c_void_p, c_char_p]),
     'rgp_softmax_xent_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'rgp_fcgru_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    'rgp_fcgru_destroy': (c_int, [c_void_p]),
+    'rgp_fcgru_workspace_bytes': (c_size_t, [c_void_p]),
+    'rgp_fcgru_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rgp_fcgru_set_weights': (c_int, [c_void_p, ctypes.POINTER(FcGruWeights), c_void_p]),
+    'rgp_fcgru_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rgp_c3d_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'rgp_c3d_destroy': (c_int, [c_void_p]),
     'rgp_c3d_workspace_bytes': (c_size_t, [c_void_p]),

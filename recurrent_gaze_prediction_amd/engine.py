@@ -190,6 +190,48 @@ def softmax_xent(logits, labels=None, want_probs=True):
     return probs, frame_loss, loss
 
 
+class FcGruEngine(object):
+    """fc-GRU gaze model (models/gaze_rnn.py:211-360, BASELINE config 2) at fixed (B, T, GH, GW)."""
+
+    def __init__(self, batch, n_steps, gazemap_hw=(49, 49), dtype='f32', device='cuda:0'):
+        self.lib = _lib.load()
+        self.device = _require_gpu(device)
+        self.B, self.T, self.GH, self.GW = int(batch), int(n_steps), int(gazemap_hw[0]), int(gazemap_hw[1])
+        self.dtype = dtype
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_fcgru_create(ctypes.byref(self._h), self.B, self.T, self.GH, self.GW,
+                                                 _lib.DTYPES[dtype]))
+            nbytes = self.lib.rgp_fcgru_workspace_bytes(self._h)
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.rgp_fcgru_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
+        self.weights = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self.lib.rgp_fcgru_destroy(h)
+
+    def set_weights(self, params):
+        w = {k: _as_dev_f32(params[k], self.device) for k in _lib.FcGruWeights.FIELDS}
+        st = _lib.FcGruWeights()
+        for k in _lib.FcGruWeights.FIELDS:
+            setattr(st, k, w[k].data_ptr())
+        self.weights = w
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_fcgru_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def forward(self, c3d_input, want_probs=True):
+        x = c3d_input
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert tuple(x.shape) == (self.B, self.T, 1024, 7, 7), tuple(x.shape)
+        logits = torch.empty(self.B, self.T, self.GH, self.GW, device=self.device)
+        probs = torch.empty_like(logits) if want_probs else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_fcgru_forward(self._h, _ptr(x), _ptr(logits), _ptr(probs), _stream_ptr(self.device)))
+        return logits, probs
+
+
 class C3DEngine(object):
     """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
 

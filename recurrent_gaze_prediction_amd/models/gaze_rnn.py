@@ -78,11 +78,33 @@ class GazePredictionGRU(ModelBase):
 
     @staticmethod
     def create_gazeprediction_network(frame_images, c3d_input, dropout_keep_prob=1.0, net=None, model=None):
-        raise NotImplementedError('fc-GRU graph (gaze_rnn.py:211-360, config 2) has no HIP path yet; '
-                                  'use models.gaze_grcn.GazePredictionGRCN')
+        """gaze_rnn.py:211-360: 1024->32 projection, GRUCell(7*7*32+49), linear read-out, on the HIP
+        path (rgp_fcgru_*).  The ShallowNet branch the reference also builds (:256-275) does not reach
+        the output and is not evaluated.  Dropout on the projected features (keep 0.5 in training,
+        SURVEY 9-Q2) is not applied: this class is inference-only here."""
+        from .. import synthetic
+        from ..engine import FcGruEngine
+        assert model is not None
+        if net is None:
+            net = {}
+        engine = FcGruEngine(model.batch_size, model.n_lstm_steps, (model.gazemap_height, model.gazemap_width),
+                             dtype=getattr(model.config, 'compute_dtype', 'f32'), device=model.session.device)
+        model.variables = synthetic.fcgru_params(getattr(model.config, 'init_seed', 0), model.gazemap_height,
+                                                 model.gazemap_width)
+        engine.set_weights(model.variables)
+        net['variables'] = model.variables
+        return engine
+
+    def state_dict(self):
+        return {k: np.array(v, copy=True) for k, v in self.variables.items()}
+
+    def load_state_dict(self, state):
+        self.variables = {k: np.asarray(v, np.float32) for k, v in state.items()}
+        self.engine.set_weights(self.variables)
 
     def build_train_op(self):
-        """gaze_rnn.py:448-478 + base.py:262-308: gradients of the loss w.r.t. every non-ShallowNet
+        """(training is implemented for the gaze_grcn engine; other engines run inference only)
+        gaze_rnn.py:448-478 + base.py:262-308: gradients of the loss w.r.t. every non-ShallowNet
         variable, clip_by_global_norm(max_grad_norm), AdamOptimizer(lr schedule).  Here: the engine's
         backward + fused Adam kernels; with WORLD_SIZE > 1 the flat gradient bucket is all-reduced
         (mean) over RCCL before the clip, so the clip sees the global-batch gradient."""
@@ -119,7 +141,7 @@ class GazePredictionGRU(ModelBase):
         x = torch.as_tensor(np.asarray(c3d, dtype=np.float32) if not torch.is_tensor(c3d) else c3d)
         x = x.to(self.session.device, torch.float32).reshape(self.batch_size, self.n_lstm_steps, 1024, 7, 7).contiguous()
         want_probs = self.config.loss_type in ('xentropy', 'KLD')
-        logits, probs = self.engine.forward(x, want_probs=want_probs)
+        logits, probs = self.engine.forward(x, want_probs=want_probs)[:2]
         self.predicted_gazemaps_logit = logits
         self.predicted_gazemaps = probs if want_probs else logits
         return self.predicted_gazemaps
