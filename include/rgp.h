@@ -154,6 +154,27 @@ int rgp_fcgru_set_weights(rgp_fcgru_t* plan, const rgp_fcgru_weights* w, rgp_str
 /* c3d_input [B,T,1024,7,7] -> logits [B,T,GH,GW]; probs (optional) = per-frame softmax. */
 int rgp_fcgru_forward(rgp_fcgru_t* plan, const float* c3d_input, float* logits, float* probs, rgp_stream_t stream);
 
+/* ------------------------------------------------------------------ frame-wise ShallowNet */
+typedef struct rgp_shallownet rgp_shallownet_t;
+
+/* SaliencyModel.create_shallownet variables (models/saliency_shallownet.py:90-185), fp32 device
+ * pointers: conv1_w [5,5,3,32] conv2_w [3,3,32,64] conv3_w [3,3,64,32] (HWIO) + biases;
+ * fc1_w [n_flat, 4802] (n_flat = 3872 at 98x98, 4608 at 112x112), fc2_w [2401, 4802] + biases. */
+typedef struct rgp_shallownet_weights {
+  const float *conv1_w, *conv1_b, *conv2_w, *conv2_b, *conv3_w, *conv3_b;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} rgp_shallownet_weights;
+
+int rgp_shallownet_create(rgp_shallownet_t** plan, int max_frames, int image_hw, int dtype);
+int rgp_shallownet_destroy(rgp_shallownet_t* plan);
+size_t rgp_shallownet_workspace_bytes(const rgp_shallownet_t* plan);
+int rgp_shallownet_bind_workspace(rgp_shallownet_t* plan, void* workspace, size_t bytes, rgp_stream_t stream);
+int rgp_shallownet_set_weights(rgp_shallownet_t* plan, const rgp_shallownet_weights* w, rgp_stream_t stream);
+/* frames [n,H,W,3] fp32 in [0,1] -> saliency [n,49,49] (saliency_shallownet.py:213); saliency7
+ * (optional) [n,7,7] = its 7x7 average pool (gaze_rnn.py:262-269). */
+int rgp_shallownet_forward(rgp_shallownet_t* plan, const float* frames, int n_frames, float* saliency,
+                           float* saliency7, rgp_stream_t stream);
+
 /* ------------------------------------------------------------------ C3D conv stack */
 typedef struct rgp_c3d rgp_c3d_t;
 

@@ -37,6 +37,11 @@ class FcGruWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in FIELDS]
 
 
+class ShallowNetWeights(ctypes.Structure):
+    FIELDS = ('conv1_w', 'conv1_b', 'conv2_w', 'conv2_b', 'conv3_w', 'conv3_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')
+    _fields_ = [(n, c_void_p) for n in FIELDS]
+
+
 class C3DWeights(ctypes.Structure):
     _fields_ = [('w', c_void_p * 8), ('b', c_void_p * 8)]
 
@@ -66,6 +71,12 @@ SIGNATURES = {
     'rgp_fcgru_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'rgp_fcgru_set_weights': (c_int, [c_void_p, ctypes.POINTER(FcGruWeights), c_void_p]),
     'rgp_fcgru_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rgp_shallownet_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
+    'rgp_shallownet_destroy': (c_int, [c_void_p]),
+    'rgp_shallownet_workspace_bytes': (c_size_t, [c_void_p]),
+    'rgp_shallownet_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rgp_shallownet_set_weights': (c_int, [c_void_p, ctypes.POINTER(ShallowNetWeights), c_void_p]),
+    'rgp_shallownet_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'rgp_c3d_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'rgp_c3d_destroy': (c_int, [c_void_p]),
     'rgp_c3d_workspace_bytes': (c_size_t, [c_void_p]),

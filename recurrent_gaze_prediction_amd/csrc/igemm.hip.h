@@ -138,6 +138,25 @@ template <typename TO, bool BIAS, bool RELU> struct EpiStore {
   }
 };
 
+// ShallowNet fully-connected layers (saliency_shallownet.py:139-185): relu(acc + bias) then
+// maxout over the two halves of the layer.  The filter is packed with the halves
+// interleaved (packed column 2j = unit j, 2j+1 = unit j + N/2), so the maxout partner of a
+// column is its neighbour and 8 packed columns give 4 outputs at column n0/2.
+template <typename TO> struct EpiReluMaxout {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    const int nvalid = N - n0;
+    if (nvalid <= 0) return;
+    TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + (n0 >> 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (2 * i + 1 < nvalid) {
+        const float a = fmaxf(v[2 * i] + e.bias[n0 + 2 * i], 0.f), b = fmaxf(v[2 * i + 1] + e.bias[n0 + 2 * i + 1], 0.f);
+        dst[i] = Elem<TO>::to(fmaxf(a, b));
+      }
+    }
+  }
+};
+
 // out (fp32) += acc : the second contribution to the carried state gradient in BPTT.
 struct EpiAccumF32 {
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {

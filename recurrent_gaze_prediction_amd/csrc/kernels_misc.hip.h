@@ -36,7 +36,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                           const int* __restrict__ tap_src, int ntaps, int cin_k,
                                                           int cin_src, int n_rows, int row0, int K, long long s_tap,
-                                                          long long s_n, long long s_c, int k0, int grouped) {
+                                                          long long s_n, long long s_c, int k0, int grouped, int row_step) {
   const long long total = (long long)n_rows * ntaps * cin_k;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % cin_k);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restric
     const int ts = tap_src ? tap_src[tap] : tap;
     float v = 0.f;
     if (ts >= 0 && c < cin_src) v = src[ts * s_tap + n * s_n + c * s_c];
-    dst[(long long)(row0 + n) * K + tap * cin_k + k0 + c] = Elem<T>::to(v);
+    dst[(long long)(row0 + n * row_step) * K + tap * cin_k + k0 + c] = Elem<T>::to(v);
   }
 }
 
@@ -152,6 +152,59 @@ __global__ __launch_bounds__(256) void video_prep_kernel(const float* __restrict
     out[o + 2] = Elem<T>::to(s[2]);
     out[o + 3] = Elem<T>::to(0.f);
   }
+}
+
+// frames [N][H][W][3] f32 -> [N][H][W][4] of T (4th channel 0): 5 kx taps x 4 channels of the
+// ShallowNet's 5x5 conv1 are then one contiguous run per ky (saliency_shallownet.py:90-97).
+template <typename T>
+__global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict__ v, T* __restrict__ out, long long npix) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const float* s = v + i * 3;
+    T* o = out + i * 4;
+    o[0] = Elem<T>::to(s[0]);
+    o[1] = Elem<T>::to(s[1]);
+    o[2] = Elem<T>::to(s[2]);
+    o[3] = Elem<T>::to(0.f);
+  }
+}
+
+// tf.nn.max_pool(ksize k, stride s, padding SAME) on NHWC (saliency_shallownet.py:117,134):
+// out = ceil(in/s), pad_before = max((out-1)*s + k - in, 0) / 2, padded cells ignored.
+// dst row stride ld_out elements per image (lets the flattened result be K-padded for the FC GEMM).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_same_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H,
+                                                           int W, int C, int k, int s, int OH, int OW, int pt, int pl,
+                                                           long long ld_out) {
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int ox = (int)((i / C) % OW);
+    const int oy = (int)((i / ((long long)C * OW)) % OH);
+    const long long n = i / ((long long)C * OW * OH);
+    float m = -INFINITY;
+    for (int a = 0; a < k; ++a) {
+      const int y = oy * s - pt + a;
+      if (y < 0 || y >= H) continue;
+      for (int b = 0; b < k; ++b) {
+        const int x = ox * s - pl + b;
+        if (x < 0 || x >= W) continue;
+        m = fmaxf(m, Elem<T>::from(src[((n * H + y) * W + x) * C + c]));
+      }
+    }
+    dst[n * ld_out + ((long long)oy * OW + ox) * C + c] = Elem<T>::to(m);
+  }
+}
+
+// 49x49 -> 7x7 average pool (tf.nn.avg_pool 7x7 stride 7 VALID, gaze_rnn.py:262-269)
+static __global__ __launch_bounds__(64) void avgpool7_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+  const long long f = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t >= 49) return;
+  const int oy = t / 7, ox = t % 7;
+  float a = 0.f;
+  for (int y = 0; y < 7; ++y)
+    for (int x = 0; x < 7; ++x) a += src[f * 2401 + (oy * 7 + y) * 49 + ox * 7 + x];
+  dst[f * 49 + t] = a * (1.0f / 49.0f);
 }
 
 // conv5b rows [F*49][d*512+c] (T) -> the reference's feature layout

@@ -112,13 +112,14 @@ int upload_desc(const ConvDesc& d, char* ws, hipStream_t s);
 
 template <typename T>
 int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int row0, hipStream_t s, int k0 = 0,
-                int grouped = 0) {
+                int grouped = 0, int row_step = 1) {
   // grouped != 0: the packed K axis holds several source filters side by side per tap (column
   // offset k0, cin_src channels each); the buffer is pre-zeroed, padding is never written.
   const long long total = (long long)n_rows * d.pack_taps * d.cin_k;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   pack_filter_kernel<T><<<blocks, 256, 0, s>>>(src, (T*)(ws + d.w_off), (const int*)(ws + d.tap_src_off), d.pack_taps,
-                                               d.cin_k, d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_n, d.s_c, k0, grouped);
+                                               d.cin_k, d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_n, d.s_c, k0, grouped,
+                                               row_step);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }

@@ -232,6 +232,50 @@ class FcGruEngine(object):
         return logits, probs
 
 
+class ShallowNetEngine(object):
+    """Frame-wise ShallowNet (models/saliency_shallownet.py:74-216, BASELINE config 1)."""
+
+    def __init__(self, max_frames, image_hw=98, dtype='f32', device='cuda:0'):
+        self.lib = _lib.load()
+        self.device = _require_gpu(device)
+        self.max_frames, self.image_hw, self.dtype = int(max_frames), int(image_hw), dtype
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_shallownet_create(ctypes.byref(self._h), self.max_frames, self.image_hw,
+                                                      _lib.DTYPES[dtype]))
+            nbytes = self.lib.rgp_shallownet_workspace_bytes(self._h)
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.rgp_shallownet_bind_workspace(self._h, _ptr(self.workspace), nbytes,
+                                                              _stream_ptr(self.device)))
+        self.weights = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self.lib.rgp_shallownet_destroy(h)
+
+    def set_weights(self, params):
+        w = {k: _as_dev_f32(params[k], self.device) for k in _lib.ShallowNetWeights.FIELDS}
+        st = _lib.ShallowNetWeights()
+        for k in _lib.ShallowNetWeights.FIELDS:
+            setattr(st, k, w[k].data_ptr())
+        self.weights = w
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_shallownet_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def forward(self, frames, want_7x7=False):
+        """frames [n,H,W,3] fp32 device tensor -> (saliency [n,49,49], saliency7 [n,7,7] or None)."""
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous()
+        n = frames.shape[0]
+        assert tuple(frames.shape[1:]) == (self.image_hw, self.image_hw, 3) and n <= self.max_frames
+        sal = torch.empty(n, 49, 49, device=self.device)
+        sal7 = torch.empty(n, 7, 7, device=self.device) if want_7x7 else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_shallownet_forward(self._h, _ptr(frames), n, _ptr(sal), _ptr(sal7),
+                                                       _stream_ptr(self.device)))
+        return sal, sal7
+
+
 class C3DEngine(object):
     """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
 
