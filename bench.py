@@ -183,8 +183,18 @@ def main():
             flops = HEAD_FLOPS[kname] * F * args.steps
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
+        # this is the committed rocprofv3 measurement (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this
+        # same command, gfx950 x2 FETCH correction applied: profiles/r01_traffic_dominant_kernel.json),
+        # scaled by the windows one launch processes here; null when it does not describe this run.
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic_dominant_kernel.json')
+        if c3d is not None and args.dtype == 'bf16' and os.path.exists(tpath):
+            tr = json.load(open(tpath))
+            if tr.get('kernel') == kname:
+                traffic = round(tr['hbm_bytes_per_window'] * min(args.c3d_chunk, F))
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / peak, 4), 'traffic': None, 'kernel': kname,
+                    'frac': round(achieved / peak, 4), 'traffic': traffic, 'kernel': kname,
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
                     'algorithmic_gflop_per_launch': round(flops / max(calls, 1) / 1e9, 3)}
         flops_frame = HEAD_FLOPS_FRAME + (C3D_FLOPS_FRAME if c3d is not None else 0.0)

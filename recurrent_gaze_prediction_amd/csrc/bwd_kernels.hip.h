@@ -133,25 +133,28 @@ __global__ __launch_bounds__(256) void head_fold_dgrad_kernel(const float* __res
 }
 
 // ... and w.r.t. the folded filter: dGp[u,v,c] += sum_{f,y,x} dz[f,y,x] * d2pad[f, y+u, x+v, c].
-// One block per (frame, output row y); partial sums over the row's 49 pixels, float atomics
-// into the 1568-entry gradient (the adds from different blocks are the only contention).
+// One block per frame; float atomics into the 1568-entry gradient (one add per element per frame).
 template <typename T>
 __global__ __launch_bounds__(256) void head_fold_wgrad_kernel(const float* __restrict__ dz, const T* __restrict__ d2pad,
                                                               float* __restrict__ dgp) {
-  __shared__ float s_dz[49];
-  const int f = blockIdx.y, y = blockIdx.x;
-  if (threadIdx.x < 49) s_dz[threadIdx.x] = dz[((long long)f * 49 + y) * 49 + threadIdx.x];
+  // one block per frame: each thread owns (tap, 8 channels) and sweeps the frame's 2401 pixels,
+  // so a frame contributes ONE atomic per gradient element (per-row blocks contended 49x more)
+  __shared__ float s_dz[2401];
+  const int f = blockIdx.x;
+  for (int i = threadIdx.x; i < 2401; i += 256) s_dz[i] = dz[(long long)f * 2401 + i];
   __syncthreads();
   const T* img = d2pad + (long long)f * 55 * 55 * 32;
   for (int it = threadIdx.x; it < 49 * 4; it += 256) {        // (tap, 8-channel group)
     const int tap = it >> 2, cg = it & 3;
     const int u = tap / 7, v = tap % 7;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const T* row = img + ((long long)(y + u) * 55 + v) * 32 + cg * 8;
-    for (int x = 0; x < 49; ++x) {
-      const float d = s_dz[x];
+    for (int y = 0; y < 49; ++y) {
+      const T* row = img + ((long long)(y + u) * 55 + v) * 32 + cg * 8;
+      for (int x = 0; x < 49; ++x) {
+        const float d = s_dz[y * 49 + x];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += d * Elem<T>::from(row[x * 32 + i]);
+        for (int i = 0; i < 8; ++i) acc[i] += d * Elem<T>::from(row[x * 32 + i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) atomicAdd(dgp + tap * 32 + cg * 8 + i, acc[i]);

@@ -94,7 +94,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   dlogits_kernel<<<F, 256, 0, s>>>(loss_l2 ? logits : probs, labels, Fp(b->dz), Fp(b->frame_sum), 2401, 1.0f / (float)F, loss_l2);
   sum_kernel<<<1, 256, 0, s>>>(Fp(b->frame_sum), (float*)gr->out_b, F, 1.0f);
   // 2. folded 7x7 filter: wgrad -> dF3, d out_W ; dgrad -> dd2
-  head_fold_wgrad_kernel<T><<<dim3(49, F), 256, 0, s>>>(Fp(b->dz), Tp(g->D2), Fp(b->dgp));
+  head_fold_wgrad_kernel<T><<<F, 256, 0, s>>>(Fp(b->dz), Tp(g->D2), Fp(b->dgp));
   head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
   head_fold_dgrad_kernel<T><<<dim3(49, F), 256, 0, s>>>(Fp(b->dz), Fp(b->gp), Tp(b->dd2));
   RGP_HIP(hipGetLastError());
