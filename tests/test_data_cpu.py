@@ -1,0 +1,80 @@
+"""CPU: the feature / batch wire format and the TF checkpoint mapping (8f-4)."""
+import numpy as np
+import pytest
+
+from recurrent_gaze_prediction_amd import checkpoint, data
+from recurrent_gaze_prediction_amd import synthetic as syn
+
+
+def test_c3d_file_roundtrip_and_fold(tmp_path):
+    feats = syn.c3d_features(1, 1, 5)[0]                       # [5,1024,7,7], channel = c*2+d
+    path = str(tmp_path / 'clip.c3d')
+    data.write_c3d_file(path, feats)
+    import pickle
+    raw = pickle.load(open(path, 'rb'))
+    assert raw.shape == (5, 1, 512, 2, 7, 7) and raw.dtype == np.float32        # extract_C3D_features.py:763-798
+    back = data.read_c3d_file(path)
+    assert back.shape == (5, 512, 2, 7, 7)
+    assert np.array_equal(data.fold_c3d(back[None], 1)[0], feats)              # gaze_rnn.py:494-497
+    data.write_c3d_file(path, feats[:1])
+    assert data.read_c3d_file(path).shape == (1, 512, 2, 7, 7)
+
+
+def test_seq2batch_matches_reference_semantics():
+    x = np.arange(10 * 2).reshape(10, 2)
+    s = data.seq2batch(x, 4)                                    # 10 > 4: two full chunks + the LAST 4 frames
+    assert s.shape == (3, 4, 2) and np.array_equal(s[0], x[:4]) and np.array_equal(s[1], x[4:8]) and np.array_equal(s[2], x[-4:])
+    s = data.seq2batch(x, 10)                                   # equal length: tiled (x2) then cut
+    assert s.shape == (1, 10, 2) and np.array_equal(s[0], x)
+    s = data.seq2batch(x[:3], 8)                                # short clip: tile_count = 8//3+1 = 3
+    assert s.shape == (1, 8, 2) and np.array_equal(s[0], np.tile(x[:3], (3, 1))[:8])
+    s = data.seq2batch(['a', 'b', 'c'], 2)
+    assert s.shape == (2, 2) and list(s[1]) == ['b', 'c']
+
+
+def test_dataset_next_batch_wraps_like_the_reference():
+    n = 5
+    ds = data.CRCDataSet(np.zeros((n, 2, 4, 4, 3), np.float32), np.ones((n, 2, 49, 49), np.float32),
+                         np.ones((n, 2, 49, 49), np.float32), np.zeros((n, 2, 512, 2, 7, 7), np.float32),
+                         np.zeros((n, 2)), ['c%d' % i for i in range(n)])
+    assert len(ds) == 5
+    assert ds.next_batch(2)[5] == ['c0', 'c1'] and ds.next_batch(2)[5] == ['c2', 'c3']
+    b = ds.next_batch(2)                                        # would run past the end -> restart the epoch
+    assert b[5] == ['c0', 'c1'] and ds.epochs_completed == 1 and ds.index_in_epoch == 2
+    sh = data.CRCDataSet(np.zeros((n, 1)), np.zeros((n, 1)), np.zeros((n, 1)), np.arange(n)[:, None], np.zeros(n),
+                         list('abcde'), shuffle=True)
+    perm = list(range(n))
+    np.random.RandomState(3027300).shuffle(perm)
+    assert [int(v) for v in sh.c3ds[:, 0]] == perm and sh.clipnames == [list('abcde')[i] for i in perm]
+
+
+def test_clip_to_dataset_chunks_a_clip():
+    n, T = 9, 4
+    feats = syn.c3d_features(2, 1, n)[0].reshape(n, 512, 2, 7, 7)
+    ds = data.clip_to_dataset(np.zeros((n, 8, 8, 3), np.float32), np.ones((n, 49, 49), np.float32),
+                              np.ones((n, 49, 49), np.float32), feats, np.zeros(n), 'clipA', T)
+    assert len(ds) == 3
+    images, maps, fix, c3d, pupils, names = ds.next_batch(3)
+    assert c3d.shape == (3, T, 512, 2, 7, 7) and np.array_equal(c3d[2], feats[-T:]) and names[0] == 'clipA#0'
+
+
+def test_tf_checkpoint_mapping_roundtrip():
+    T = 3
+    state = syn.grcn_params(4, T, random_bn=True)
+    tf_vars = checkpoint.export_tf_variables(state)
+    assert 'RGP/batch_normalization/gamma' in tf_vars and 'RGP/batch_normalization_2/beta' in tf_vars
+    assert 'RGP/RCNBottom/GRU_Conv_Wz' in tf_vars and 'RGP/Upsampling/weight3' in tf_vars
+    tf_vars = {k + ':0': v for k, v in tf_vars.items()}
+    tf_vars.update({'RGP/out_W/Adam:0': np.zeros((12, 1)), 'global_step:0': np.array(7),
+                    'RGP/batch_normalization/moving_mean:0': np.zeros(128),
+                    'RGP/batch_normalization_1/moving_variance:0': np.ones(128)})
+    back = checkpoint.import_tf_variables(tf_vars)
+    assert set(back) == set(state)
+    for k in state:
+        assert np.array_equal(back[k], state[k]), k
+    del tf_vars['RGP/batch_normalization_1/gamma:0']
+    with pytest.raises(KeyError):
+        checkpoint.import_tf_variables(tf_vars)
+    with pytest.raises(ValueError):
+        checkpoint.import_tf_variables(dict(checkpoint.export_tf_variables(state),
+                                            **{'RGP/batch_normalization/moving_mean': np.full(128, 0.3)}))
