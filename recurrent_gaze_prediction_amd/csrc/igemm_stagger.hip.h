@@ -112,6 +112,26 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
                                        16, 0, 0);
   };
 
+  // one third of a K-tile's DMA (2 of this wave's 6 instructions): issued between MFMA groups
+  auto stage_part = [&](int st, int kt, int part, long long ko) {
+    char* abuf = smem + st * STAGE;
+    char* bbuf = abuf + BM * 128;
+    if (part < 2) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[part * 2 + j] + ko),
+                                         (__attribute__((address_space(3))) void*)(abuf + (wave * A_PER_WAVE + part * 2 + j) * 1024),
+                                         16, 0, 0);
+    } else {
+      const long long kb = (long long)kt * 128;
+#pragma unroll
+      for (int j = 0; j < B_PER_WAVE; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[j] + kb),
+                                         (__attribute__((address_space(3))) void*)(bbuf + (wave * B_PER_WAVE + j) * 1024),
+                                         16, 0, 0);
+    }
+  };
+
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -133,16 +153,38 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
   __builtin_amdgcn_s_barrier();
   if (group_b) __builtin_amdgcn_s_barrier();      // run one half-step behind group A
 
+  // diagnostic build only (ABLATE & 32): per-wave s_memtime stamps around the phases; sums go to a
+  // debug buffer (EpiParams::c_save, unused by the C3D epilogue) that nothing else reads.
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_start = 0;
+  auto stamp = [&](int k) {
+    if (ABLATE & 32) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (k >= 0) seg[k] += t - t_prev;
+      else t_start = t;
+      t_prev = t;
+    }
+  };
+  stamp(-1);
   int st = 0;       // stage of K-tile j
 #pragma clang loop unroll(disable)
   for (int j = 0; j < p.nk; ++j) {
     // ---------------- LOAD(j) ----------------
+    // Order inside the phases (measured with the s_memtime stamps below): fragment reads are issued
+    // first so their LDS latency is covered by the DMA issue, and the B-tile DMA (2 of this wave's 6
+    // instructions) rides in COMPUTE(j) so LOAD and COMPUTE are closer in length.  ABLATE & 128 is the
+    // earlier order (all 6 DMA, then reads) kept for A/B runs.
+    constexpr bool READS_FIRST = !(ABLATE & 128);
+    constexpr bool B_IN_COMPUTE = !(ABLATE & 128);
     const bool more = j + 2 < p.nk;
-    if (more && !(ABLATE & 2)) {
-      int st2 = st + 2;
-      if (st2 >= 3) st2 -= 3;
-      stage(st2, j + 2);
-    }
+    int st2 = st + 2;
+    if (st2 >= 3) st2 -= 3;
+    long long ko2 = 0;
+    if (more) ko2 = (long long)s_koff[j + 2] * ESZ;
+    if (!READS_FIRST && more && !(ABLATE & 2)) stage(st2, j + 2);
+    stamp(0);
     const char* sb = smem + ((ABLATE & 4) ? 0 : st) * STAGE;
     f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
@@ -155,27 +197,55 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       bf[0][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc0);
       bf[1][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc1);
     }
-    if (more && !(ABLATE & 2)) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stamp(1);
+    if (READS_FIRST && more && !(ABLATE & 2)) {
+      __builtin_amdgcn_sched_barrier(0);
+      stage_part(st2, j + 2, 0, ko2);
+      stage_part(st2, j + 2, 1, ko2);
+      if (!B_IN_COMPUTE) stage_part(st2, j + 2, 2, ko2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // everything older than this phase's own DMA (i.e. all of K-tile j+1) must have landed
+    if (more && !(ABLATE & 2)) {
+      if (B_IN_COMPUTE) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    stamp(2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    stamp(3);
     // ---------------- COMPUTE(j) ----------------
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int jn = 0; jn < NI; ++jn) {
           if (ABLATE & 1) { asm volatile("" ::"v"(af[s][i]), "v"(bf[s][jn])); acc[i][jn][0] += 1.f; }
           else Mma<T>::step(acc[i][jn], af[s][i], bf[s][jn]);
         }
+        if (B_IN_COMPUTE && more && !(ABLATE & 2) && s * MI + i == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_part(st2, j + 2, 2, ko2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
+    stamp(4);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    stamp(5);
     st = st + 1 == 3 ? 0 : st + 1;
+  }
+  if ((ABLATE & 32) && e.c_save && lane == 0) {
+    unsigned long long* dbg = (unsigned long long*)e.c_save + ((size_t)blockIdx.x * 8 + wave) * 8;
+    seg[6] = t_prev - t_start;
+    for (int k = 0; k < 8; ++k) dbg[k] = seg[k];
   }
   if (!group_b) __builtin_amdgcn_s_barrier();
   __syncthreads();

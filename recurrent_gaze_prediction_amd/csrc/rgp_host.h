@@ -173,6 +173,8 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
       if (abl == 6) return launch_stagger<T, P, Epi, 6>(p, e, s);
       if (abl == 3) return launch_stagger<T, P, Epi, 3>(p, e, s);
       if (abl == 5) return launch_stagger<T, P, Epi, 5>(p, e, s);
+      if (abl == 32) return launch_stagger<T, P, Epi, 32>(p, e, s);
+      if (abl == 128) return launch_stagger<T, P, Epi, 128>(p, e, s);
     }
     return launch_stagger<T, P, Epi>(p, e, s);
   }
