@@ -179,6 +179,12 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
     return launch_stagger<T, P, Epi>(p, e, s);
   }
   if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
+  // latency-bound problems (the per-timestep recurrent convs: M = B*49): 64x64 tiles give 4x the
+  // blocks of 128x128, so more of the 256 CUs have a tile
+  {
+    const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (ksplit == 1 && p.N >= 64 && tiles128 * ksplit < 160) return launch_cfg<T, 64, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
+  }
   if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s, ksplit);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
   return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s, ksplit);

@@ -52,3 +52,35 @@ def test_grcn_forward_matches_oracle(gpu, dtype, B, T, P, S):
     ref_probs = torch_ref.softmax_maps(torch.tensor(ref_logits)).numpy()
     assert rel_err(probs.cpu().numpy(), ref_probs) < tol, 'softmax maps'
     assert np.allclose(probs.cpu().numpy().reshape(B, T, -1).sum(-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_long_recurrence_reference_default_T42(gpu, dtype):
+    """T = 42 is the reference's default n_lstm_steps (gaze_rnn.py:50): rounding compounds over the
+    recurrence, so the last frames are the hard case for bf16 operands."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    B, T = 2, 42
+    p = syn.grcn_params(21, T, gru_std=0.02, random_bn=True)
+    x = syn.c3d_features(22, B, T)
+    ref_logits, ref_h, _ = oracle_forward(x, p)
+    eng = GrcnEngine(B, T, dtype=dtype, device=gpu)
+    eng.set_weights(p)
+    logits, _ = eng.forward(torch.tensor(x, device=gpu))
+    got = logits.cpu().numpy()
+    assert rel_err(got, ref_logits) < TOL[dtype]
+    assert rel_err(got[:, -1], ref_logits[:, -1]) < TOL[dtype], 'last timestep'
+    h = eng.read_buffer('rcn_outputs').cpu().numpy().reshape(ref_h.shape)
+    assert np.sqrt(((h[:, -1] - ref_h[:, -1]) ** 2).mean()) / np.sqrt((ref_h[:, -1] ** 2).mean()) < TOL_H_RMS[dtype]
+
+
+def test_single_clip_single_step_edge(gpu):
+    """B = 1, T = 1: one M-tile with 79 clamped rows, one timestep (h_0 = 0 path only)."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    p = syn.grcn_params(23, 1, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(24, 1, 1)
+    ref_logits, _, _ = oracle_forward(x, p)
+    eng = GrcnEngine(1, 1, dtype='f32', device=gpu)
+    eng.set_weights(p)
+    logits, probs = eng.forward(torch.tensor(x, device=gpu))
+    assert rel_err(logits.cpu().numpy(), ref_logits) < TOL['f32']
+    assert abs(probs.sum().item() - 1.0) < 1e-5
