@@ -175,6 +175,37 @@ int rgp_shallownet_set_weights(rgp_shallownet_t* plan, const rgp_shallownet_weig
 int rgp_shallownet_forward(rgp_shallownet_t* plan, const float* frames, int n_frames, float* saliency,
                            float* saliency7, rgp_stream_t stream);
 
+/* ------------------------------------------------------------------ two-level cascade (config 5) */
+typedef struct rgp_cascade rgp_cascade_t;
+
+/* Variables of GazePredictionGRCN in models/gaze_grcn_cascade.py (fp32 device pointers):
+ * proj_c3d_W [1,1,1024,512] + b (:269-275); bottom cell filters GRU_Conv_* (3x3, 512 -> 256, :290-303);
+ * Upsampling/weight [11,11,64,256] (:317-321); top cell filters (5x5, x: [5,5,65,3], h: [5,5,3,3],
+ * :346-357, input = concat(upsampled [64], ShallowNet saliency [1]));
+ * fc1_w [7203,4802] fc2_w [2401,4802] + biases (:383-423); the ShallowNet's own variables. */
+typedef struct rgp_cascade_weights {
+  const float *proj_c3d_W, *proj_c3d_b;
+  const float *bottom_Wz, *bottom_Uz, *bottom_Wr, *bottom_Ur, *bottom_W, *bottom_U;
+  const float* upsampling_weight;
+  const float *top_Wz, *top_Uz, *top_Wr, *top_Ur, *top_W, *top_U;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  rgp_shallownet_weights shallownet;
+} rgp_cascade_weights;
+
+int rgp_cascade_create(rgp_cascade_t** plan, int batch, int n_steps, int image_hw, int dtype);
+int rgp_cascade_destroy(rgp_cascade_t* plan);
+size_t rgp_cascade_workspace_bytes(const rgp_cascade_t* plan);
+int rgp_cascade_bind_workspace(rgp_cascade_t* plan, void* workspace, size_t bytes, rgp_stream_t stream);
+int rgp_cascade_set_weights(rgp_cascade_t* plan, const rgp_cascade_weights* w, rgp_stream_t stream);
+/* frame_images [B*T,H,W,3] fp32 in [0,1], c3d_input [B,T,1024,7,7] -> gazemaps [B,T,49,49]
+ * (predicted_gazemaps of gaze_grcn_cascade.py:423, trained with loss_type l2). */
+int rgp_cascade_forward(rgp_cascade_t* plan, const float* frame_images, const float* c3d_input, float* gazemaps,
+                        rgp_stream_t stream);
+/* Intermediates of the last forward as dense fp32 (net[...] keys of gaze_grcn_cascade.py):
+ * "frm_sal" [B*T,49,49], "rcn_outputs" [B,T,7,7,256], "rcn_upsampled_outputs" [B*T,49,49,64],
+ * "gaze_rcn_outputs" [B*T,49,49,3] (top-cell states). */
+int rgp_cascade_read_buffer(rgp_cascade_t* plan, const char* name, float* dst, rgp_stream_t stream);
+
 /* ------------------------------------------------------------------ C3D conv stack */
 typedef struct rgp_c3d rgp_c3d_t;
 

@@ -36,7 +36,12 @@ def conv2d_same(x_nhwc, w_hwio):
 def conv2d_transpose(x_nhwc, f_hwoi, stride, padding):
     """tf.nn.conv2d_transpose with filter [kh,kw,out,in] (gaze_grcn.py:326-358)."""
     w = f_hwoi.permute(3, 2, 0, 1)            # torch: [in, out, kh, kw]
-    pad = 0 if padding == 'VALID' else f_hwoi.shape[0] // 2
+    pad = 0
+    if padding == 'SAME':                     # TF SAME: output = input*stride, crop pad_before
+        k, n = f_hwoi.shape[0], x_nhwc.shape[1]
+        total = max((n - 1) * stride + k - n * stride, 0)
+        assert total % 2 == 0, 'asymmetric SAME crop not needed by any reference layer'
+        pad = total // 2
     y = F.conv_transpose2d(x_nhwc.permute(0, 3, 1, 2), w, stride=stride, padding=pad)
     return y.permute(0, 2, 3, 1)
 
@@ -175,6 +180,38 @@ def shallownet_forward(images_nhwc, p):
     x = torch.relu(x @ p['fc2_w'] + p['fc2_b'])
     x = torch.maximum(x[:, :2401], x[:, 2401:])
     return x.reshape(-1, 49, 49)
+
+
+# --------------------------------------------------------------------------- cascade (config 5)
+def cascade_forward(frame_images, c3d_input, p, want_all=False):
+    """gaze_grcn_cascade.py:188-423 as intended (the top cell sees
+    concat(upsampled bottom state, ShallowNet saliency), the commented block :370-377).
+    frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] -> gazemaps [B,T,49,49]."""
+    b, t = c3d_input.shape[:2]
+    sal = shallownet_forward(frame_images.reshape((-1,) + tuple(frame_images.shape[2:])), p['ShallowNet'])
+    sal = sal.reshape(b, t, 49, 49, 1)                                           # :235-244
+    xr = c3d_input.permute(0, 1, 3, 4, 2)
+    emb = (xr.reshape(-1, 1024) @ p['proj_c3d_W'] + p['proj_c3d_b']).reshape(b, t, 7, 7, -1)   # :262-275
+    bot = {k[len('RCNBottom/'):]: v for k, v in p.items() if k.startswith('RCNBottom/')}
+    top = {k[len('RCNGaze/'):]: v for k, v in p.items() if k.startswith('RCNGaze/')}
+    h = torch.zeros(b, 7, 7, bot['GRU_Conv_Uz'].shape[-1], dtype=c3d_input.dtype)
+    g = torch.zeros(b, 49, 49, top['GRU_Conv_Uz'].shape[-1], dtype=c3d_input.dtype)
+    outs, ups, hs, gs = [], [], [], []
+    for i in range(t):
+        h = grcn_cell(emb[:, i], h, bot)                                         # :307
+        up = conv2d_transpose(h, p['Upsampling/weight'], 7, 'SAME')              # :327-333
+        g = grcn_cell(torch.cat([up, sal[:, i]], -1), g, top)                    # :370-379
+        x = g.reshape(b, -1)                                                     # :383
+        x = torch.relu(x @ p['LastProjection/fc1_w'] + p['LastProjection/fc1_b'])
+        x = torch.maximum(x[:, :2401], x[:, 2401:])
+        x = torch.relu(x @ p['LastProjection/fc2_w'] + p['LastProjection/fc2_b'])
+        x = torch.maximum(x[:, :2401], x[:, 2401:])
+        outs.append(x.reshape(b, 49, 49))
+        ups.append(up); hs.append(h); gs.append(g)
+    maps = torch.stack(outs, 1)
+    if want_all:
+        return maps, dict(sal=sal[..., 0], bottom=torch.stack(hs, 1), up=torch.stack(ups, 1), top=torch.stack(gs, 1))
+    return maps
 
 
 # --------------------------------------------------------------------------- C3D conv stack

@@ -42,6 +42,13 @@ class ShallowNetWeights(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in FIELDS]
 
 
+class CascadeWeights(ctypes.Structure):
+    FIELDS = ('proj_c3d_W', 'proj_c3d_b', 'bottom_Wz', 'bottom_Uz', 'bottom_Wr', 'bottom_Ur', 'bottom_W', 'bottom_U',
+              'upsampling_weight', 'top_Wz', 'top_Uz', 'top_Wr', 'top_Ur', 'top_W', 'top_U',
+              'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')
+    _fields_ = [(n, c_void_p) for n in FIELDS] + [('shallownet', ShallowNetWeights)]
+
+
 class C3DWeights(ctypes.Structure):
     _fields_ = [('w', c_void_p * 8), ('b', c_void_p * 8)]
 
@@ -77,6 +84,13 @@ SIGNATURES = {
     'rgp_shallownet_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'rgp_shallownet_set_weights': (c_int, [c_void_p, ctypes.POINTER(ShallowNetWeights), c_void_p]),
     'rgp_shallownet_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'rgp_cascade_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    'rgp_cascade_destroy': (c_int, [c_void_p]),
+    'rgp_cascade_workspace_bytes': (c_size_t, [c_void_p]),
+    'rgp_cascade_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'rgp_cascade_set_weights': (c_int, [c_void_p, ctypes.POINTER(CascadeWeights), c_void_p]),
+    'rgp_cascade_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'rgp_cascade_read_buffer': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
     'rgp_c3d_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'rgp_c3d_destroy': (c_int, [c_void_p]),
     'rgp_c3d_workspace_bytes': (c_size_t, [c_void_p]),

@@ -276,6 +276,76 @@ class ShallowNetEngine(object):
         return sal, sal7
 
 
+class CascadeEngine(object):
+    """Two-level cascade (models/gaze_grcn_cascade.py:188-423, BASELINE config 5), forward."""
+
+    # rgp_cascade_weights field -> key of the parameter dictionary (TF variable names)
+    KEYS = (('proj_c3d_W', 'proj_c3d_W'), ('proj_c3d_b', 'proj_c3d_b'),
+            ('bottom_Wz', 'RCNBottom/GRU_Conv_Wz'), ('bottom_Uz', 'RCNBottom/GRU_Conv_Uz'),
+            ('bottom_Wr', 'RCNBottom/GRU_Conv_Wr'), ('bottom_Ur', 'RCNBottom/GRU_Conv_Ur'),
+            ('bottom_W', 'RCNBottom/GRU_Conv_W'), ('bottom_U', 'RCNBottom/GRU_Conv_U'),
+            ('upsampling_weight', 'Upsampling/weight'),
+            ('top_Wz', 'RCNGaze/GRU_Conv_Wz'), ('top_Uz', 'RCNGaze/GRU_Conv_Uz'),
+            ('top_Wr', 'RCNGaze/GRU_Conv_Wr'), ('top_Ur', 'RCNGaze/GRU_Conv_Ur'),
+            ('top_W', 'RCNGaze/GRU_Conv_W'), ('top_U', 'RCNGaze/GRU_Conv_U'),
+            ('fc1_w', 'LastProjection/fc1_w'), ('fc1_b', 'LastProjection/fc1_b'),
+            ('fc2_w', 'LastProjection/fc2_w'), ('fc2_b', 'LastProjection/fc2_b'))
+
+    def __init__(self, batch, n_steps, image_hw=98, dtype='bf16', device='cuda:0'):
+        self.lib = _lib.load()
+        self.device = _require_gpu(device)
+        self.batch, self.n_steps, self.image_hw, self.dtype = int(batch), int(n_steps), int(image_hw), dtype
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_cascade_create(ctypes.byref(self._h), self.batch, self.n_steps, self.image_hw,
+                                                   _lib.DTYPES[dtype]))
+            nbytes = self.lib.rgp_cascade_workspace_bytes(self._h)
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.rgp_cascade_bind_workspace(self._h, _ptr(self.workspace), nbytes,
+                                                           _stream_ptr(self.device)))
+        self.weights = None
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self.lib.rgp_cascade_destroy(h)
+
+    def set_weights(self, params):
+        st = _lib.CascadeWeights()
+        w = {}
+        for field, key in self.KEYS:
+            w[field] = _as_dev_f32(params[key], self.device)
+            setattr(st, field, w[field].data_ptr())
+        for k in _lib.ShallowNetWeights.FIELDS:
+            w['shallownet.' + k] = _as_dev_f32(params['ShallowNet'][k], self.device)
+            setattr(st.shallownet, k, w['shallownet.' + k].data_ptr())
+        self.weights = w
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_cascade_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def forward(self, frame_images, c3d_input):
+        """frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] fp32 device tensors -> maps [B,T,49,49]."""
+        B, T = self.batch, self.n_steps
+        assert frame_images.is_cuda and frame_images.dtype == torch.float32 and frame_images.is_contiguous()
+        assert c3d_input.is_cuda and c3d_input.dtype == torch.float32 and c3d_input.is_contiguous()
+        assert tuple(frame_images.shape) == (B, T, self.image_hw, self.image_hw, 3), tuple(frame_images.shape)
+        assert tuple(c3d_input.shape) == (B, T, 1024, 7, 7), tuple(c3d_input.shape)
+        maps = torch.empty(B, T, 49, 49, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_cascade_forward(self._h, _ptr(frame_images), _ptr(c3d_input), _ptr(maps),
+                                                    _stream_ptr(self.device)))
+        return maps
+
+    BUFFERS = {'frm_sal': lambda B, T: (B, T, 49, 49), 'rcn_outputs': lambda B, T: (B, T, 7, 7, 256),
+               'rcn_upsampled_outputs': lambda B, T: (B, T, 49, 49, 64), 'gaze_rcn_outputs': lambda B, T: (B, T, 49, 49, 3)}
+
+    def read_buffer(self, name):
+        out = torch.empty(self.BUFFERS[name](self.batch, self.n_steps), device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_cascade_read_buffer(self._h, name.encode(), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+
 class C3DEngine(object):
     """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
 

@@ -104,6 +104,27 @@ def shallownet_params(seed, image_hw=98):
     }
 
 
+def cascade_params(seed, image_hw=98, dim_proj=512, dim_state=256, gru_std=0.03, top_std=0.05):
+    """Weights of the cascade model (gaze_grcn_cascade.py:228-423) keyed by TF variable names
+    (scopes RCNBottom / RCNGaze / LastProjection / ShallowNet).  The reference initialises the GRU
+    filters with stddev 1e-4; tests use larger values so that the recurrence carries signal."""
+    rs = np.random.RandomState(seed)
+    u = lambda *s: rs.uniform(-0.1, 0.1, size=s).astype(np.float32)
+    p = {'proj_c3d_W': u(1024, dim_proj), 'proj_c3d_b': u(dim_proj)}
+    for n, cin in (('Wz', dim_proj), ('Uz', dim_state), ('Wr', dim_proj), ('Ur', dim_state), ('W', dim_proj),
+                   ('U', dim_state)):
+        p['RCNBottom/GRU_Conv_' + n] = _trunc_normal(rs, (3, 3, cin, dim_state), gru_std)
+    p['Upsampling/weight'] = _xavier_conv(rs, (11, 11, 64, dim_state))
+    for n, cin in (('Wz', 65), ('Uz', 3), ('Wr', 65), ('Ur', 3), ('W', 65), ('U', 3)):
+        p['RCNGaze/GRU_Conv_' + n] = _trunc_normal(rs, (5, 5, cin, 3), top_std)
+    p['LastProjection/fc1_w'] = _xavier_fc(rs, 49 * 49 * 3, 4802) * 4.0
+    p['LastProjection/fc1_b'] = u(4802) * 0.1
+    p['LastProjection/fc2_w'] = _xavier_fc(rs, 2401, 4802)
+    p['LastProjection/fc2_b'] = u(4802) * 0.1
+    p['ShallowNet'] = shallownet_params(seed + 1, image_hw)
+    return p
+
+
 def c3d_params(seed, scale='he'):
     """C3D conv1a..conv5b weights, DHWIO [3,3,3,Cin,Cout] + bias [Cout].
 

@@ -88,7 +88,8 @@ def test_softmax_xent_matches_definition():
 
 
 # ------------------------------------------------------------------ two restatements agree
-@pytest.mark.parametrize('stride,pad,k,hin,hout', [(3, 'VALID', 5, 7, 23), (2, 'VALID', 5, 23, 49), (1, 'SAME', 7, 49, 49)])
+@pytest.mark.parametrize('stride,pad,k,hin,hout', [(3, 'VALID', 5, 7, 23), (2, 'VALID', 5, 23, 49), (1, 'SAME', 7, 49, 49),
+                                                     (7, 'SAME', 11, 7, 49)])     # last: gaze_grcn_cascade.py:327-333
 def test_conv2d_transpose_numpy_vs_torch(stride, pad, k, hin, hout):
     rs = np.random.RandomState(6)
     y, f = rs.randn(2, hin, hin, 5), rs.randn(k, k, 3, 5)
@@ -204,3 +205,29 @@ def test_autograd_grads_match_finite_differences():
         fd = (vals[0] - vals[1]) / (2 * eps)
         an = grads[key][idx].item()
         assert abs(fd - an) < 1e-6 * max(1.0, abs(an)) + 1e-8, (key, fd, an)
+
+
+def test_cascade_oracle_closed_forms():
+    """gaze_grcn_cascade.py:346-423: with a zero top cell the read-out is a constant of the FC biases;
+    the top cell's first step from the zero state is (1 - u) * c of its input convolutions."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    p = syn.cascade_params(21)
+    tt = lambda d: {k: tt(v) if isinstance(v, dict) else torch.tensor(v, dtype=torch.float64) for k, v in d.items()}
+    rs = np.random.RandomState(22)
+    frames, c3d = torch.tensor(rs.rand(1, 2, 98, 98, 3)), torch.tensor(syn.c3d_features(23, 1, 2), dtype=torch.float64)
+    maps, mid = torch_ref.cascade_forward(frames, c3d, tt(p), want_all=True)
+    assert tuple(maps.shape) == (1, 2, 49, 49) and tuple(mid['up'].shape) == (1, 2, 49, 49, 64)
+    x = torch.cat([mid['up'][:, 0], mid['sal'][:, 0, :, :, None]], -1)
+    q = tt(p)
+    u = torch.sigmoid(torch_ref.conv2d_same(x, q['RCNGaze/GRU_Conv_Wz']))
+    c = torch.tanh(torch_ref.conv2d_same(x, q['RCNGaze/GRU_Conv_W']))
+    assert torch.allclose(mid['top'][:, 0], (1 - u) * c, atol=1e-12)
+    z = dict(p)
+    for k in list(z):
+        if k.startswith('RCNGaze/'):
+            z[k] = np.zeros_like(z[k])
+    maps0 = torch_ref.cascade_forward(frames, c3d, tt(z)).numpy()
+    f1 = np.maximum(p['LastProjection/fc1_b'], 0).astype(np.float64)
+    f1 = np.maximum(f1[:2401], f1[2401:])
+    f2 = np.maximum(f1 @ p['LastProjection/fc2_w'].astype(np.float64) + p['LastProjection/fc2_b'], 0)
+    assert np.allclose(maps0, np.broadcast_to(np.maximum(f2[:2401], f2[2401:]).reshape(49, 49), maps0.shape), atol=1e-12)
