@@ -227,6 +227,19 @@ int rgp_c3d_set_weights(rgp_c3d_t* plan, const rgp_c3d_weights* w, rgp_stream_t 
  * form rgp_grcn_forward_rows consumes. */
 int rgp_c3d_forward(rgp_c3d_t* plan, const float* video, int n_windows, float* features, void* rows,
                     rgp_stream_t stream);
+/* The VIDEO_DATA layer (feature_extration.prototxt:3-21) + rgp_c3d_forward in one call: frames is a
+ * device stack [n_frames, frame_h, frame_w, 3] of 8-bit pixels in the channel order the weights were
+ * trained with (OpenCV BGR for the Sports-1M model); window w is the 16 consecutive frames from
+ * window_starts[w] (HOST int32 array; extract_C3D_features.py:866 uses 0, 16, 32, ...).  Each frame is
+ * resized to 128x171 (bilinear), centre-cropped to 112x112 and mean_cube [3,16,128,171] (device fp32,
+ * the parsed sport1m_train16_128_mean.binaryproto; NULL = no subtraction) is subtracted. */
+int rgp_c3d_forward_frames(rgp_c3d_t* plan, const unsigned char* frames, int n_frames, int frame_h, int frame_w,
+                           const int* window_starts, int n_windows, const float* mean_cube, float* features, void* rows,
+                           rgp_stream_t stream);
+/* Only the VIDEO_DATA step: writes video [n_windows,16,112,112,3] fp32 (what rgp_c3d_forward takes). */
+int rgp_c3d_frames_to_video(rgp_c3d_t* plan, const unsigned char* frames, int n_frames, int frame_h, int frame_w,
+                            const int* window_starts, int n_windows, const float* mean_cube, float* video,
+                            rgp_stream_t stream);
 /* Copies layer i's (0..7) pooled, post-ReLU output, un-padded fp32 NDHWC, into dst. */
 int rgp_c3d_read_layer(rgp_c3d_t* plan, int layer, int n_windows, float* dst, rgp_stream_t stream);
 size_t rgp_c3d_layer_elems(const rgp_c3d_t* plan, int layer, int n_windows);

@@ -97,6 +97,10 @@ SIGNATURES = {
     'rgp_c3d_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'rgp_c3d_set_weights': (c_int, [c_void_p, ctypes.POINTER(C3DWeights), c_void_p]),
     'rgp_c3d_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'rgp_c3d_forward_frames': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    'rgp_c3d_frames_to_video': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p,
+                                        c_void_p, c_void_p]),
     'rgp_c3d_read_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'rgp_c3d_layer_elems': (c_size_t, [c_void_p, c_int, c_int]),
     'rgp_grcn_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(GrcnWeights), c_int, c_void_p]),

@@ -154,6 +154,57 @@ __global__ __launch_bounds__(256) void video_prep_kernel(const float* __restrict
   }
 }
 
+// The VIDEO_DATA layer of the C3D prototxt (feature_extration.prototxt:3-21) on device: window w is the
+// 16 consecutive uint8 frames from starts[w]; each is resized to 128x171 (bilinear, half-pixel centres,
+// edge-clamped, rounded back to an 8-bit level as cv::resize stores it), centre-cropped to 112x112
+// (offsets 8, 29), and the mean cube [3][16][128][171] is subtracted at the cropped position.
+// Writes the halo-padded operand image of conv1a (layout of video_prep_kernel) and/or a dense fp32
+// [N][16][112][112][3] copy.  One thread per output pixel; 4 source taps x 3 channels each.
+template <typename T>
+__global__ __launch_bounds__(256) void frames_prep_kernel(const unsigned char* __restrict__ frames, int fh, int fw,
+                                                          const int* __restrict__ starts, const float* __restrict__ mean,
+                                                          T* __restrict__ out, float* __restrict__ video, long long npix) {
+  constexpr int D = 16, H = 112, W = 112, RH = 128, RW = 171, OY = (RH - H) / 2, OX = (RW - W) / 2;
+  const float sy = (float)fh / RH, sx = (float)fw / RW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int z = (int)((i / ((long long)W * H)) % D);
+    const long long n = i / ((long long)W * H * D);
+    const int ry = y + OY, rx = x + OX;
+    float fy = (ry + 0.5f) * sy - 0.5f, fx = (rx + 0.5f) * sx - 0.5f;
+    fy = fminf(fmaxf(fy, 0.f), (float)(fh - 1));
+    fx = fminf(fmaxf(fx, 0.f), (float)(fw - 1));
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, fh - 1), x1 = min(x0 + 1, fw - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const unsigned char* f = frames + (long long)(starts[n] + z) * fh * fw * 3;
+    const unsigned char *p00 = f + ((long long)y0 * fw + x0) * 3, *p01 = f + ((long long)y0 * fw + x1) * 3;
+    const unsigned char *p10 = f + ((long long)y1 * fw + x0) * 3, *p11 = f + ((long long)y1 * fw + x1) * 3;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float top = (float)p00[c] + wx * ((float)p01[c] - (float)p00[c]);
+      const float bot = (float)p10[c] + wx * ((float)p11[c] - (float)p10[c]);
+      float r = floorf(top + wy * (bot - top) + 0.5f);
+      if (mean) r -= mean[((long long)(c * D + z) * RH + ry) * RW + rx];
+      v[c] = r;
+    }
+    if (out) {
+      const long long o = (((n * (D + 2) + z + 1) * (H + 2) + y + 1) * (long long)(W + 4) + x + 1) * 4;
+      out[o + 0] = Elem<T>::to(v[0]);
+      out[o + 1] = Elem<T>::to(v[1]);
+      out[o + 2] = Elem<T>::to(v[2]);
+      out[o + 3] = Elem<T>::to(0.f);
+    }
+    if (video) {
+      video[i * 3 + 0] = v[0];
+      video[i * 3 + 1] = v[1];
+      video[i * 3 + 2] = v[2];
+    }
+  }
+}
+
 // frames [N][H][W][3] f32 -> [N][H][W][4] of T (4th channel 0): 5 kx taps x 4 channels of the
 // ShallowNet's 5x5 conv1 are then one contiguous run per ky (saliency_shallownet.py:90-97).
 template <typename T>

@@ -38,6 +38,7 @@ struct rgp_c3d {
   long long act_stride[9] = {0}; // elements per window
   std::vector<int> unpad_tab[8];
   size_t unpad_off[8] = {0};
+  size_t starts_off = 0;         // int32 [max_windows] first-frame index of each window (frames entry)
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool weights_set = false;
@@ -149,12 +150,23 @@ int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   }
 }
 
+// raw uint8 frames of one chunk of windows (the VIDEO_DATA layer's job)
+struct FrameSrc {
+  const unsigned char* frames = nullptr;
+  int fh = 0, fw = 0;
+  const float* mean = nullptr;
+};
+
 template <typename T>
-int forward_chunk(rgp_c3d* c, const float* video, int n, float* features, void* rows, hipStream_t s) {
+int forward_chunk(rgp_c3d* c, const float* video, const FrameSrc* fs, int n, float* features, void* rows, hipStream_t s) {
   const long long npix = (long long)n * 16 * 112 * 112;
+  const int blocks = (int)std::min<long long>((npix + 255) / 256, 65536);
   int pid = c->prof.begin(8, s);
-  video_prep_kernel<T><<<(int)std::min<long long>((npix + 255) / 256, 65536), 256, 0, s>>>(
-      video, (T*)(c->ws + c->act_off[0]), npix, 16, 112, 112);
+  if (fs)
+    frames_prep_kernel<T><<<blocks, 256, 0, s>>>(fs->frames, fs->fh, fs->fw, (const int*)(c->ws + c->starts_off), fs->mean,
+                                                 (T*)(c->ws + c->act_off[0]), nullptr, npix);
+  else
+    video_prep_kernel<T><<<blocks, 256, 0, s>>>(video, (T*)(c->ws + c->act_off[0]), npix, 16, 112, 112);
   RGP_HIP(hipGetLastError());
   c->prof.end(pid, s);
   for (int i = 0; i < 8; ++i) {
@@ -275,6 +287,7 @@ int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) {
     }
   }
   c->act_stride[8] = 49LL * 1024;
+  c->starts_off = a.take((size_t)max_windows * 4);
   if (!ok) { delete c; return set_err(RGP_EINVAL, "rgp_c3d_create: K schedule failed"); }
   for (int i = 0; i < 9; ++i) c->act_off[i] = a.take((size_t)max_windows * c->act_stride[i] * esize(dtype));
   c->ws_bytes = a.off;
@@ -330,7 +343,59 @@ int rgp_c3d_forward(rgp_c3d_t* c, const float* video, int n_windows, float* feat
     const float* v = video + (size_t)w0 * 16 * 112 * 112 * 3;
     float* f = features ? features + (size_t)w0 * 1024 * 49 : nullptr;
     void* r = rows ? (char*)rows + (size_t)w0 * 49 * 1024 * es : nullptr;
-    RGP_TRY(c->dtype == RGP_BF16 ? forward_chunk<bf16_t>(c, v, n, f, r, s) : forward_chunk<float>(c, v, n, f, r, s));
+    RGP_TRY(c->dtype == RGP_BF16 ? forward_chunk<bf16_t>(c, v, nullptr, n, f, r, s)
+                                 : forward_chunk<float>(c, v, nullptr, n, f, r, s));
+  }
+  return RGP_OK;
+}
+
+static int check_windows(const int* starts, int n_windows, int n_frames, const char* who) {
+  for (int w = 0; w < n_windows; ++w)
+    if (starts[w] < 0 || (long long)starts[w] + 16 > n_frames)
+      return set_err(RGP_EINVAL, "%s: window %d starts at frame %d but only %d frames were given", who, w, starts[w], n_frames);
+  return RGP_OK;
+}
+
+int rgp_c3d_forward_frames(rgp_c3d_t* c, const unsigned char* frames, int n_frames, int frame_h, int frame_w,
+                           const int* window_starts, int n_windows, const float* mean_cube, float* features, void* rows,
+                           rgp_stream_t stream) {
+  RGP_REQUIRE(c && frames && window_starts && n_windows > 0 && n_frames >= 16 && frame_h > 0 && frame_w > 0,
+              "rgp_c3d_forward_frames: bad arguments");
+  RGP_REQUIRE((long long)n_frames * frame_h * frame_w * 3 < (1LL << 40), "rgp_c3d_forward_frames: frame stack too large");
+  if (!c->ws) return set_err(RGP_EWORKSPACE, "rgp_c3d: workspace not bound");
+  if (!c->weights_set) return set_err(RGP_ESTATE, "rgp_c3d: weights not set");
+  RGP_TRY(check_windows(window_starts, n_windows, n_frames, "rgp_c3d_forward_frames"));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t es = esize(c->dtype);
+  FrameSrc fs;
+  fs.frames = frames; fs.fh = frame_h; fs.fw = frame_w; fs.mean = mean_cube;
+  for (int w0 = 0; w0 < n_windows; w0 += c->max_windows) {
+    const int n = std::min(c->max_windows, n_windows - w0);
+    RGP_HIP(hipMemcpyAsync(c->ws + c->starts_off, window_starts + w0, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    float* f = features ? features + (size_t)w0 * 1024 * 49 : nullptr;
+    void* r = rows ? (char*)rows + (size_t)w0 * 49 * 1024 * es : nullptr;
+    RGP_TRY(c->dtype == RGP_BF16 ? forward_chunk<bf16_t>(c, nullptr, &fs, n, f, r, s)
+                                 : forward_chunk<float>(c, nullptr, &fs, n, f, r, s));
+  }
+  return RGP_OK;
+}
+
+int rgp_c3d_frames_to_video(rgp_c3d_t* c, const unsigned char* frames, int n_frames, int frame_h, int frame_w,
+                            const int* window_starts, int n_windows, const float* mean_cube, float* video,
+                            rgp_stream_t stream) {
+  RGP_REQUIRE(c && frames && window_starts && video && n_windows > 0 && n_frames >= 16 && frame_h > 0 && frame_w > 0,
+              "rgp_c3d_frames_to_video: bad arguments");
+  if (!c->ws) return set_err(RGP_EWORKSPACE, "rgp_c3d: workspace not bound");
+  RGP_TRY(check_windows(window_starts, n_windows, n_frames, "rgp_c3d_frames_to_video"));
+  hipStream_t s = (hipStream_t)stream;
+  for (int w0 = 0; w0 < n_windows; w0 += c->max_windows) {
+    const int n = std::min(c->max_windows, n_windows - w0);
+    RGP_HIP(hipMemcpyAsync(c->ws + c->starts_off, window_starts + w0, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    const long long npix = (long long)n * 16 * 112 * 112;
+    frames_prep_kernel<float><<<(int)std::min<long long>((npix + 255) / 256, 65536), 256, 0, s>>>(
+        frames, frame_h, frame_w, (const int*)(c->ws + c->starts_off), mean_cube, nullptr,
+        video + (size_t)w0 * 16 * 112 * 112 * 3, npix);
+    RGP_HIP(hipGetLastError());
   }
   return RGP_OK;
 }

@@ -394,6 +394,40 @@ class C3DEngine(object):
             _lib.check(self.lib.rgp_c3d_forward(self._h, _ptr(video), n, _ptr(feats), _ptr(rows), _stream_ptr(self.device)))
         return feats, rows
 
+    def _frames_args(self, frames, window_starts, mean_cube):
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
+        assert frames.shape[3] == 3, tuple(frames.shape)
+        starts = [int(v) for v in window_starts]
+        arr = (ctypes.c_int * len(starts))(*starts)
+        if mean_cube is not None:
+            assert mean_cube.is_cuda and mean_cube.dtype == torch.float32 and mean_cube.is_contiguous()
+            assert tuple(mean_cube.shape) == (3, 16, 128, 171), tuple(mean_cube.shape)
+        return arr, len(starts)
+
+    def forward_frames(self, frames, window_starts, mean_cube=None, want_features=True, want_rows=False, out_rows=None):
+        """frames [N,H,W,3] uint8 device tensor, window_starts: first frame of each 16-frame window
+        -> (features [n,1024,7,7] fp32, rows): the VIDEO_DATA layer + conv1a..conv5b."""
+        arr, n = self._frames_args(frames, window_starts, mean_cube)
+        feats = torch.empty(n, 1024, 7, 7, device=self.device) if want_features else None
+        rows = out_rows
+        if want_rows and rows is None:
+            rows = torch.empty(n * 49, 1024, dtype=self.torch_dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_forward_frames(self._h, _ptr(frames), frames.shape[0], frames.shape[1],
+                                                       frames.shape[2], arr, n, _ptr(mean_cube), _ptr(feats), _ptr(rows),
+                                                       _stream_ptr(self.device)))
+        return feats, rows
+
+    def frames_to_video(self, frames, window_starts, mean_cube=None):
+        """The VIDEO_DATA step alone -> video [n,16,112,112,3] fp32 (the input of forward())."""
+        arr, n = self._frames_args(frames, window_starts, mean_cube)
+        video = torch.empty(n, 16, 112, 112, 3, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_frames_to_video(self._h, _ptr(frames), frames.shape[0], frames.shape[1],
+                                                        frames.shape[2], arr, n, _ptr(mean_cube), _ptr(video),
+                                                        _stream_ptr(self.device)))
+        return video
+
     def read_layer(self, layer, n_windows):
         n = self.lib.rgp_c3d_layer_elems(self._h, layer, n_windows)
         out = torch.empty(n, dtype=torch.float32, device=self.device)

@@ -1,0 +1,212 @@
+"""CPU: the C3D front-end's host logic -- blob files, protobuf model files, the
+Caffe -> DHWIO weight converter, window scheduling, and the VIDEO_DATA-layer oracle."""
+import os
+import pickle
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import c3d_frontend as ofe
+from recurrent_gaze_prediction_amd import c3d_frontend as fe
+from recurrent_gaze_prediction_amd import data as rdata
+from recurrent_gaze_prediction_amd import synthetic as syn
+
+
+# ------------------------------------------------------------------ binary blobs
+def test_binary_blob_known_bytes_and_round_trip(tmp_path):
+    """extract_C3D_features.py:13-76: 5 little-endian int32 dims [num,channel,length,height,width], then fp32
+    row-major data."""
+    p = str(tmp_path / 'x.conv5b')
+    vals = np.arange(2 * 3 * 1 * 2 * 2, dtype=np.float32) * 0.5
+    with open(p, 'wb') as f:
+        f.write(struct.pack('<5i', 2, 3, 1, 2, 2) + vals.tobytes())
+    s, blob, ok = fe.read_binary_blob(p)
+    assert ok == 1 and list(s) == [2, 3, 1, 2, 2]
+    assert blob.data.shape == (2, 3, 1, 2, 2) and blob.data.dtype == np.float32
+    assert blob.data[1, 2, 0, 1, 0] == vals[((1 * 3 + 2) * 1 + 0) * 4 + 2]
+    q = str(tmp_path / 'y.conv5b')
+    fe.write_binary_blob(q, blob.data)
+    assert open(p, 'rb').read() == open(q, 'rb').read()
+
+
+def test_binary_blob_truncated_reports_status_0(tmp_path):
+    p = str(tmp_path / 'bad.conv5b')
+    with open(p, 'wb') as f:
+        f.write(struct.pack('<5i', 1, 512, 2, 7, 7) + b'\0' * 100)
+    s, blob, ok = fe.read_binary_blob(p)
+    assert ok == 0 and list(s) == [] and list(blob.data) == []
+    with open(p, 'wb') as f:
+        f.write(b'\1\0\0')
+    assert fe.read_binary_blob(p)[2] == 0
+
+
+def test_process_c3d_features_matches_dot_c3d_reader(tmp_path):
+    """Per-window blobs -> `<video>.c3d` (extract_C3D_features.py:763-798) -> data.read_c3d_file."""
+    rs = np.random.RandomState(0)
+    vdir = tmp_path / 'feats' / 'clipA'
+    os.makedirs(str(vdir))
+    feats = rs.rand(3, 1, 512, 2, 7, 7).astype(np.float32)
+    for i, s in enumerate((0, 16, 32)):
+        fe.write_binary_blob(str(vdir / ('%06d.conv5b' % (s + 1))), feats[i])
+    out = fe.process_c3d_features(str(vdir), 'conv5b')
+    assert out == str(tmp_path / 'feats' / 'clipA.c3d')
+    with open(out, 'rb') as f:
+        got = pickle.load(f)
+    assert got.shape == (3, 1, 512, 2, 7, 7) and np.array_equal(got, feats)
+    assert np.array_equal(np.asarray(rdata.read_c3d_file(out)).reshape(feats.shape), feats)
+
+
+# ------------------------------------------------------------------ scheduling
+def test_window_starts_and_input_list():
+    assert fe.window_starts(50) == [0, 16, 32]                       # range(0, n, 16), incomplete tail dropped
+    assert fe.window_starts(50, drop_incomplete=False) == [0, 16, 32, 48]
+    assert fe.window_starts(15) == [] and fe.window_starts(16) == [0]
+    ins, outs = fe.input_list_lines('/frames', '/feat', 'vid7', [0, 16])
+    assert ins == ['/frames/vid7/ 1 0 ', '/frames/vid7/ 17 0 ']     # extract_C3D_features.py:677 (1-based, dummy label)
+    assert outs[1].endswith('/feat/vid7/000017')
+
+
+# ------------------------------------------------------------------ protobuf model files
+def _pb_classes():
+    """The C3D fork's messages built with the protobuf runtime: an encoder independent of ours."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    L = descriptor_pb2.FieldDescriptorProto
+    fdp = descriptor_pb2.FileDescriptorProto(name='c3d_caffe_test.proto', package='c3dtest', syntax='proto2')
+    blob = fdp.message_type.add(name='BlobProto')
+    for i, n in enumerate(['num', 'channels', 'length', 'height', 'width']):
+        blob.field.add(name=n, number=i + 1, type=L.TYPE_INT32, label=L.LABEL_OPTIONAL)
+    blob.field.add(name='data', number=6, type=L.TYPE_FLOAT, label=L.LABEL_REPEATED).options.packed = True
+    blob.field.add(name='diff', number=7, type=L.TYPE_FLOAT, label=L.LABEL_REPEATED).options.packed = True
+    lp = fdp.message_type.add(name='LayerParameter')
+    lp.field.add(name='name', number=1, type=L.TYPE_STRING, label=L.LABEL_OPTIONAL)
+    lp.field.add(name='type', number=2, type=L.TYPE_STRING, label=L.LABEL_OPTIONAL)
+    lp.field.add(name='num_output', number=3, type=L.TYPE_UINT32, label=L.LABEL_OPTIONAL)
+    lp.field.add(name='blobs', number=50, type=L.TYPE_MESSAGE, label=L.LABEL_REPEATED, type_name='.c3dtest.BlobProto')
+    lc = fdp.message_type.add(name='LayerConnection')
+    lc.field.add(name='layer', number=1, type=L.TYPE_MESSAGE, label=L.LABEL_OPTIONAL, type_name='.c3dtest.LayerParameter')
+    lc.field.add(name='bottom', number=2, type=L.TYPE_STRING, label=L.LABEL_REPEATED)
+    lc.field.add(name='top', number=3, type=L.TYPE_STRING, label=L.LABEL_REPEATED)
+    net = fdp.message_type.add(name='NetParameter')
+    net.field.add(name='name', number=1, type=L.TYPE_STRING, label=L.LABEL_OPTIONAL)
+    net.field.add(name='layers', number=2, type=L.TYPE_MESSAGE, label=L.LABEL_REPEATED, type_name='.c3dtest.LayerConnection')
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fdp)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName('c3dtest.' + n))
+    return get('BlobProto'), get('NetParameter')
+
+
+def test_mean_binaryproto_parser_against_protobuf_runtime(tmp_path):
+    BlobProto, _ = _pb_classes()
+    rs = np.random.RandomState(1)
+    mean = (rs.rand(3, 16, 8, 5) * 255).astype(np.float32)
+    msg = BlobProto(num=1, channels=3, length=16, height=8, width=5)
+    msg.data.extend(mean.ravel().tolist())
+    p = str(tmp_path / 'mean.binaryproto')
+    with open(p, 'wb') as f:
+        f.write(msg.SerializeToString())
+    got = fe.read_mean_binaryproto(p)
+    assert got.shape == (3, 16, 8, 5) and np.array_equal(got, mean)
+    q = str(tmp_path / 'mean2.binaryproto')
+    fe.write_mean_binaryproto(q, mean)
+    assert open(p, 'rb').read() == open(q, 'rb').read()                # our encoder = the runtime's bytes
+    m2 = BlobProto()
+    m2.ParseFromString(open(q, 'rb').read())
+    assert (m2.num, m2.channels, m2.length, m2.height, m2.width) == (1, 3, 16, 8, 5)
+
+
+def test_stock_caffe_blob_without_length_field():
+    """BVLC BlobProto {num=1, channels=2, height=3, width=4, data=5}: 4 dims, data found by size."""
+    a = np.arange(24, dtype=np.float32).reshape(1, 2, 3, 4)
+    raw = b''.join(fe._enc_field(i + 1, 0, d) for i, d in enumerate(a.shape)) + fe._enc_field(5, 2, a.tobytes())
+    assert np.array_equal(fe.parse_blobproto(raw), a)
+    with pytest.raises(ValueError):
+        fe.parse_blobproto(raw[:-8])
+
+
+def test_caffemodel_parser_and_converter(tmp_path):
+    """NetParameter{layers{layer{name, type, blobs=50}}} written by the protobuf runtime -> DHWIO params:
+    W_dhwio[kd,kh,kw,ci,co] == W_caffe[co,ci,kd,kh,kw]."""
+    BlobProto, NetParameter = _pb_classes()
+    rs = np.random.RandomState(2)
+    net = NetParameter(name='DeepConv3DNet_Sport1M_Val')
+    caffe_w = {}
+    chans = dict(conv1a=(3, 4), conv2a=(4, 6), conv3a=(6, 5), conv3b=(5, 5), conv4a=(5, 7), conv4b=(7, 7), conv5a=(7, 8),
+                 conv5b=(8, 8))                                            # small stand-in widths, real layer names
+    data_layer = net.layers.add()
+    data_layer.layer.name, data_layer.layer.type = 'data', 'video_data'
+    for name in fe.C3D_LAYER_NAMES:
+        cin, cout = chans[name]
+        w = rs.randn(cout, cin, 3, 3, 3).astype(np.float32)
+        b = rs.randn(cout).astype(np.float32)
+        caffe_w[name] = (w, b)
+        lc = net.layers.add()
+        lc.layer.name, lc.layer.type, lc.layer.num_output = name, 'convolution3d', cout
+        lc.bottom.append('x')
+        lc.top.append(name)
+        wb = lc.layer.blobs.add(num=cout, channels=cin, length=3, height=3, width=3)
+        wb.data.extend(w.ravel().tolist())
+        bb = lc.layer.blobs.add(num=1, channels=1, length=1, height=1, width=cout)
+        bb.data.extend(b.tolist())
+        relu = net.layers.add()
+        relu.layer.name, relu.layer.type = 'relu_' + name, 'relu'
+    p = str(tmp_path / 'model')
+    with open(p, 'wb') as f:
+        f.write(net.SerializeToString())
+    layers = fe.read_caffemodel(p)
+    assert sorted(layers) == sorted(fe.C3D_LAYER_NAMES)                   # layers without blobs are skipped
+    params = fe.caffemodel_to_c3d_params(layers)
+    for name in fe.C3D_LAYER_NAMES:
+        w, b = caffe_w[name]
+        assert params[name + '_w'].shape == (3, 3, 3) + w.shape[1::-1]
+        assert params[name + '_w'][1, 2, 0, 1, 2] == w[2, 1, 1, 2, 0]
+        assert np.array_equal(params[name + '_w'], np.transpose(w, (2, 3, 4, 1, 0))) and np.array_equal(params[name + '_b'], b)
+    # and back: our writer's file parses with the protobuf runtime to the same blobs
+    raw = fe.c3d_params_to_caffemodel_bytes(params)
+    net2 = NetParameter()
+    net2.ParseFromString(raw)
+    assert [l.layer.name for l in net2.layers] == list(fe.C3D_LAYER_NAMES)
+    assert np.array_equal(np.array(net2.layers[1].layer.blobs[0].data, np.float32).reshape(6, 4, 3, 3, 3), caffe_w['conv2a'][0])
+    q = str(tmp_path / 'model2')
+    with open(q, 'wb') as f:
+        f.write(raw)
+    again = fe.caffemodel_to_c3d_params(fe.read_caffemodel(q))
+    assert all(np.array_equal(again[k], params[k]) for k in params)
+
+
+def test_converted_weights_have_c3d_engine_shapes():
+    p = syn.c3d_params(3)
+    raw = fe.c3d_params_to_caffemodel_bytes(p)
+    layers = {}
+    for field, wire, val in fe.iter_fields(raw):
+        if field == 2:
+            n, blobs = fe._layer_name_blobs(val)
+            layers[n] = blobs
+    assert layers['conv1a'][0].shape == (64, 3, 3, 3, 3) and layers['conv5b'][0].shape == (512, 512, 3, 3, 3)
+    q = fe.caffemodel_to_c3d_params(layers)
+    assert all(np.array_equal(q[k], p[k]) for k in p)
+
+
+# ------------------------------------------------------------------ VIDEO_DATA oracle
+def test_resize_oracle_identity_constant_and_upscale():
+    rs = np.random.RandomState(4)
+    f = rs.randint(0, 256, size=(128, 171, 3)).astype(np.uint8)
+    assert np.array_equal(ofe.resize_bilinear_u8(f), f.astype(np.float32))          # already 128x171: exact
+    c = np.full((240, 320, 3), 77, np.uint8)
+    assert np.array_equal(ofe.resize_bilinear_u8(c), np.full((128, 171, 3), 77, np.float32))
+    g = np.array([[0, 100], [200, 60]], np.uint8)[:, :, None]
+    up = ofe.resize_bilinear_u8(g, 4, 4)[:, :, 0]
+    # half-pixel centres: output x=0 -> src -0.25 (clamped to 0), x=1 -> 0.25, x=2 -> 0.75, x=3 -> 1.25 (clamped)
+    assert list(up[0]) == [0, 25, 75, 100] and list(up[:, 0]) == [0, 50, 150, 200]
+    assert up[1, 1] == np.floor((0 + 0.25 * 100) * 0.75 + (200 + 0.25 * (60 - 200)) * 0.25 + 0.5)
+
+
+def test_video_data_layer_crop_offsets_and_mean():
+    """Centre crop (8, 29) of the 128x171 frame, window frame order, mean cube indexed [c][l][h][w]."""
+    rs = np.random.RandomState(5)
+    frames = rs.randint(0, 256, size=(40, 128, 171, 3)).astype(np.uint8)
+    mean = rs.rand(3, 16, 128, 171).astype(np.float32) * 100
+    v = ofe.video_data_layer(frames, [0, 20], mean)
+    assert v.shape == (2, 16, 112, 112, 3)
+    assert v[1, 3, 5, 7, 2] == np.float32(frames[23, 13, 36, 2]) - mean[2, 3, 13, 36]
+    assert np.array_equal(ofe.video_data_layer(frames, [16])[0, 0], frames[16, 8:120, 29:141].astype(np.float32))
