@@ -244,6 +244,22 @@ int rgp_c3d_frames_to_video(rgp_c3d_t* plan, const unsigned char* frames, int n_
 int rgp_c3d_read_layer(rgp_c3d_t* plan, int layer, int n_windows, float* dst, rgp_stream_t stream);
 size_t rgp_c3d_layer_elems(const rgp_c3d_t* plan, int layer, int n_windows);
 
+/* ---- end-to-end fine-tune of the conv stack (BASELINE config 5; tf.gradients, base.py:278-281) ----
+ * rgp_c3d_create_ex(save_for_backward = 1) makes the forward record the pooling arg-max and reserves the
+ * gradient images.  After ONE forward of n_windows <= max_windows windows, rgp_c3d_backward takes the
+ * gradient w.r.t. the conv5b feature -- d_features [n,1024,7,7] fp32 (layout of `features`) or d_rows
+ * [n*49,1024] fp32 (layout of `rows`), exactly one non-NULL -- and ACCUMULATES (+=) the parameter
+ * gradients into grads, a flat fp32 vector laid out w[0] (DHWIO), b[0], w[1], b[1], ... (the caller zeroes
+ * it; rgp_c3d_param_offset gives each piece's element offset, rgp_c3d_param_elems the total). */
+int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for_backward);
+size_t rgp_c3d_param_elems(const rgp_c3d_t* plan);
+size_t rgp_c3d_param_offset(const rgp_c3d_t* plan, int layer, int is_bias);
+int rgp_c3d_backward(rgp_c3d_t* plan, const float* d_features, const float* d_rows, int n_windows, float* grads,
+                     rgp_stream_t stream);
+/* After rgp_c3d_backward: the gradient w.r.t. layer i's conv output before ReLU/pooling (what dgrad and
+ * wgrad of that layer consumed) as dense fp32 [n, D, H, W, Cout]. */
+int rgp_c3d_read_grad_image(rgp_c3d_t* plan, int layer, int n_windows, float* dst, rgp_stream_t stream);
+
 /* Per-layer timing, as rgp_grcn_profile_*: index 0..7 = conv1a..conv5b (one fused
  * conv+bias+ReLU+pool kernel launch each), 8 = video_prep. */
 #define RGP_C3D_STAGES 9

@@ -101,6 +101,11 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p]),
     'rgp_c3d_frames_to_video': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int, c_void_p,
                                         c_void_p, c_void_p]),
+    'rgp_c3d_create_ex': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
+    'rgp_c3d_param_elems': (c_size_t, [c_void_p]),
+    'rgp_c3d_param_offset': (c_size_t, [c_void_p, c_int, c_int]),
+    'rgp_c3d_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'rgp_c3d_read_grad_image': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'rgp_c3d_read_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'rgp_c3d_layer_elems': (c_size_t, [c_void_p, c_int, c_int]),
     'rgp_grcn_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(GrcnWeights), c_int, c_void_p]),

@@ -30,6 +30,7 @@ struct Conv1aParams {
   const bf16_t* wp;     // [64][160]
   const float* bias;    // [64]
   bf16_t* out;          // [n][18][58][58][64] (halo-padded input of conv2a)
+  unsigned char* argmax;  // optional [n][16][56][56][64]: dy*2+dx of the first maximum of each pool1 window
   int n_windows;
 };
 
@@ -41,6 +42,7 @@ constexpr int C1_OUT_P = 58;
 
 __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t s_out[4][8 * 72];   // per wave: 8 px x (64 ch + 8 pad)
+  __shared__ __attribute__((aligned(16))) unsigned char s_arg[4][8 * 72];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int frow = lane & 15, kg = lane >> 4;
@@ -105,6 +107,14 @@ __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aPa
         const f32x4 c = acc[mi][jn];
         const float v = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])) + bias_v[jn], 0.f);   // pool1, bias, ReLU
         so[(mi * 4 + kg) * 72 + jn * 16 + frow] = f2bf(v);
+        if (p.argmax) {
+          float best = c[0];
+          unsigned char idx = 0;
+#pragma unroll
+          for (int r = 1; r < 4; ++r)
+            if (c[r] > best) { best = c[r]; idx = (unsigned char)r; }
+          s_arg[wave][(mi * 4 + kg) * 72 + jn * 16 + frow] = idx;
+        }
       }
     __builtin_amdgcn_wave_barrier();   // wave-private LDS: DS ops of one wave execute in order
     const int px = lane >> 3, chunk = lane & 7;
@@ -115,6 +125,11 @@ __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aPa
     const long long n = t / C1_TILES_PER_WINDOW;
     const long long o = (((n * (C1_D + 2) + z + 1) * C1_OUT_P + yo + 1) * (long long)C1_OUT_P + xg * 8 + px + 1) * 64 + chunk * 8;
     *(u32x4*)(p.out + o) = row;
+    if (p.argmax) {
+      const uint2 codes = *(const uint2*)(s_arg[wave] + px * 72 + chunk * 8);
+      const long long oa = (((n * C1_D + z) * C1_PO + yo) * (long long)C1_PO + xg * 8 + px) * 64 + chunk * 8;
+      *(uint2*)(p.argmax + oa) = codes;
+    }
     __builtin_amdgcn_wave_barrier();
   };
 

@@ -96,6 +96,10 @@ struct EpiParams {
   const float* bn_gamma;     // [S] of this timestep
   const float* bn_beta;
   float bn_inv_std;
+  // training forward of pooled conv layers: index (0..P-1, window order) of the first maximum of every
+  // pooling window, [img][Mw/P][N] bytes; null = not recorded
+  unsigned char* argmax;
+  const void* mask;          // EpiStoreMask: forward output whose sign gates the gradient
 };
 
 // ---------------------------------------------------------------------------
@@ -135,6 +139,21 @@ template <typename TO, bool BIAS, bool RELU> struct EpiStore {
     }
     TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
     store8<TO>(dst, v, nvalid);
+  }
+};
+
+// dgrad through a ReLU: out = acc where the layer's forward output (e.mask, same geometry as out)
+// was positive, else 0.
+template <typename TO> struct EpiStoreMask {
+  static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    const int nvalid = N - n0;
+    if (nvalid <= 0) return;
+    const long long idx = (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
+    const TO* m = (const TO*)e.mask + idx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nvalid && !(Elem<TO>::from(m[i]) > 0.f)) v[i] = 0.f;
+    store8<TO>((TO*)e.out + idx, v, nvalid);
   }
 };
 
@@ -251,6 +270,35 @@ template <> struct Mma<float> {
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
   }
 };
+
+// max over the P rows of one pooling window (8 adjacent columns of the fp32 slab in LDS)
+template <int P> __device__ __forceinline__ void pool_window(const float* src, int ld, float* v) {
+  f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+#pragma unroll
+  for (int q = 1; q < P; ++q) {
+    const f32x4 w0 = *(const f32x4*)(src + q * ld), w1 = *(const f32x4*)(src + q * ld + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], w0[i]); v1[i] = fmaxf(v1[i], w1[i]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+}
+// same, also recording which row held the (first) maximum: 8 bytes at amax
+template <int P> __device__ __forceinline__ void pool_window_argmax(const float* src, int ld, float* v, unsigned char* amax) {
+  unsigned idx[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = src[i]; idx[i] = 0; }
+#pragma unroll
+  for (int q = 1; q < P; ++q)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float w = src[q * ld + i];
+      if (w > v[i]) { v[i] = w; idx[i] = q; }
+    }
+  const unsigned lo = idx[0] | (idx[1] << 8) | (idx[2] << 16) | (idx[3] << 24);
+  const unsigned hi = idx[4] | (idx[5] << 8) | (idx[6] << 16) | (idx[7] << 24);
+  *(uint2*)amax = make_uint2(lo, hi);
+}
 
 template <int BM, int BN> struct IgemmSmem {
   static constexpr int TILE_BYTES = (BM + BN) * 128;
@@ -428,15 +476,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
       if (img >= 0) {
         float v[8];
         const float* src = stg + (g * P) * LDS_LD + cg * 8;
-        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-#pragma unroll
-        for (int q = 1; q < P; ++q) {
-          const f32x4 w0 = *(const f32x4*)(src + q * LDS_LD), w1 = *(const f32x4*)(src + q * LDS_LD + 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], w0[i]); v1[i] = fmaxf(v1[i], w1[i]); }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+        if (P > 1 && e.argmax && n0 + cg * 8 < p.N) pool_window_argmax<P>(src, LDS_LD, v, e.argmax + ((long long)img * (p.Mw / P) + s_rowml[rt] / P) * p.N + n0 + cg * 8);
+        else pool_window<P>(src, LDS_LD, v);
         Epi::apply(e, p.N, img, s_rowml[rt] / P, n0 + cg * 8, v);
       }
     }

@@ -274,15 +274,8 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       if (img >= 0) {
         float v[8];
         const float* src = stg + (g * P) * LDS_LD + cg * 8;
-        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-#pragma unroll
-        for (int q = 1; q < P; ++q) {
-          const f32x4 w0 = *(const f32x4*)(src + q * LDS_LD), w1 = *(const f32x4*)(src + q * LDS_LD + 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], w0[i]); v1[i] = fmaxf(v1[i], w1[i]); }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+        if (P > 1 && e.argmax && n0 + cg * 8 < p.N) pool_window_argmax<P>(src, LDS_LD, v, e.argmax + ((long long)img * (p.Mw / P) + s_rowml[rt] / P) * p.N + n0 + cg * 8);
+        else pool_window<P>(src, LDS_LD, v);
         Epi::apply(e, p.N, img, s_rowml[rt] / P, n0 + cg * 8, v);
       }
     }

@@ -4,47 +4,11 @@
 // (the reference runs it as an offline Caffe binary, extract_C3D_features.py:689-724).
 #include <algorithm>
 
-#include "rgp_host.h"
+#include "rgp_c3d_plan.h"
 #include "conv1a.hip.h"
 #include "conv3d_halo.hip.h"
 
 using namespace rgp;
-
-namespace {
-struct LayerSpec {
-  int cin, cout, D, H, pd, ph;  // input extent (W == H), pooling window (depth, spatial); 1 = none
-};
-const LayerSpec kLayers[8] = {
-    {3, 64, 16, 112, 1, 2},  {64, 128, 16, 56, 2, 2}, {128, 256, 8, 28, 1, 1}, {256, 256, 8, 28, 2, 2},
-    {256, 512, 4, 14, 1, 1}, {512, 512, 4, 14, 2, 2}, {512, 512, 2, 7, 1, 1},  {512, 512, 2, 7, 1, 1},
-};
-}  // namespace
-
-// Box decomposition of one layer for conv3d_halo_kernel (tables live in the workspace).
-struct HaloDesc {
-  bool used = false;
-  int BZ = 0, BY = 0, BX = 0, HP8 = 0, nbx = 0, nby = 0, nbz = 0, bufs = 1;
-  int box_in[3] = {0, 0, 0}, box_out[3] = {0, 0, 0};
-  std::vector<int> goff, row_hp, tap_shift, out_tab;
-  size_t goff_off = 0, row_hp_off = 0, tap_shift_off = 0, out_tab_off = 0;
-  size_t smem = 0;
-};
-
-struct rgp_c3d {
-  int max_windows = 0, dtype = RGP_BF16;
-  HaloDesc halo[8];
-  ConvDesc L[8];
-  size_t act_off[9] = {0};       // act[i] = halo-padded input of layer i; act[8] = conv5b rows
-  long long act_stride[9] = {0}; // elements per window
-  std::vector<int> unpad_tab[8];
-  size_t unpad_off[8] = {0};
-  size_t starts_off = 0;         // int32 [max_windows] first-frame index of each window (frames entry)
-  size_t ws_bytes = 0;
-  char* ws = nullptr;
-  bool weights_set = false;
-  const float* bias[8] = {nullptr};
-  StageProfiler prof;
-};
 
 namespace {
 
@@ -53,6 +17,7 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
   IgemmParams p = make_params(c->L[i], c->ws + c->act_off[i], c->ws, n);
   EpiParams e = make_epi(c->L[i], c->ws + c->act_off[i + 1], c->ws);
   e.bias = c->bias[i];
+  if (c->save && P > 1) e.argmax = (unsigned char*)(c->ws + c->B[i].argmax_off);
   // dev diagnostics (RGP_ABLATE=32 RGP_STAMP=<layer>): phase stamps of the staggered kernel
   static const int stamp_layer = getenv("RGP_STAMP") ? atoi(getenv("RGP_STAMP")) : -1;
   if (stamp_layer == i && P == 8) {
@@ -84,6 +49,7 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s) {
   p.wp = (const bf16_t*)(c->ws + c->L[0].w_off);
   p.bias = c->bias[0];
   p.out = (bf16_t*)(c->ws + c->act_off[1]);
+  p.argmax = c->save ? (unsigned char*)(c->ws + c->B[0].argmax_off) : nullptr;
   p.n_windows = n;
   const long long tiles = (long long)n * C1_TILES_PER_WINDOW;
   const int grid = (int)std::min<long long>((tiles + 3) / 4, 1024);
@@ -169,6 +135,7 @@ int forward_chunk(rgp_c3d* c, const float* video, const FrameSrc* fs, int n, flo
     video_prep_kernel<T><<<blocks, 256, 0, s>>>(video, (T*)(c->ws + c->act_off[0]), npix, 16, 112, 112);
   RGP_HIP(hipGetLastError());
   c->prof.end(pid, s);
+  c->last_n = n;
   for (int i = 0; i < 8; ++i) {
     pid = c->prof.begin(i, s);
     RGP_TRY(layer_dispatch<T>(c, i, n, s));
@@ -199,17 +166,20 @@ int set_weights_impl(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
 
 extern "C" {
 
-int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) {
+int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) { return rgp_c3d_create_ex(plan, max_windows, dtype, 0); }
+
+int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for_backward) {
   RGP_REQUIRE(plan && max_windows > 0, "rgp_c3d_create: bad arguments");
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_c3d_create: dtype %d", dtype);
   RGP_REQUIRE((long long)max_windows * 16 * 112 * 112 < (1LL << 31), "rgp_c3d_create: max_windows too large");
   rgp_c3d* c = new rgp_c3d();
   c->max_windows = max_windows;
   c->dtype = dtype;
+  c->save = save_for_backward != 0;
   bool ok = true;
   Arena a;
   for (int i = 0; i < 8; ++i) {
-    const LayerSpec& l = kLayers[i];
+    const C3dLayerSpec& l = kLayers[i];
     ConvDesc& d = c->L[i];
     const int D = l.D, H = l.H, W = l.H;
     const int C = i == 0 ? 4 : l.cin;                 // conv1a: channels padded 3 -> 4
@@ -290,6 +260,10 @@ int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) {
   c->starts_off = a.take((size_t)max_windows * 4);
   if (!ok) { delete c; return set_err(RGP_EINVAL, "rgp_c3d_create: K schedule failed"); }
   for (int i = 0; i < 9; ++i) c->act_off[i] = a.take((size_t)max_windows * c->act_stride[i] * esize(dtype));
+  if (c->save) {
+    const int rc = c3d_bwd_plan(c, a);
+    if (rc != RGP_OK) { delete c; return rc; }
+  }
   c->ws_bytes = a.off;
   *plan = c;
   return RGP_OK;
@@ -321,6 +295,7 @@ int rgp_c3d_bind_workspace(rgp_c3d_t* c, void* workspace, size_t bytes, rgp_stre
       RGP_HIP(hipMemcpyAsync(c->ws + h.out_tab_off, h.out_tab.data(), h.out_tab.size() * 4, hipMemcpyHostToDevice, s));
     }
   }
+  if (c->save) RGP_TRY(c3d_bwd_upload(c, s));
   return RGP_OK;
 }
 
@@ -329,7 +304,9 @@ int rgp_c3d_set_weights(rgp_c3d_t* c, const rgp_c3d_weights* w, rgp_stream_t str
   if (!c->ws) return set_err(RGP_EWORKSPACE, "rgp_c3d: workspace not bound");
   for (int i = 0; i < 8; ++i) RGP_REQUIRE(w->w[i] && w->b[i], "rgp_c3d_set_weights: layer %d pointer is null", i);
   hipStream_t s = (hipStream_t)stream;
-  return c->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(c, w, s) : set_weights_impl<float>(c, w, s);
+  RGP_TRY(c->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(c, w, s) : set_weights_impl<float>(c, w, s));
+  if (c->save) RGP_TRY(c3d_bwd_pack(c, w, s));
+  return RGP_OK;
 }
 
 int rgp_c3d_forward(rgp_c3d_t* c, const float* video, int n_windows, float* features, void* rows, rgp_stream_t stream) {

@@ -1,0 +1,337 @@
+// librgp_hip.so: backward of the C3D conv stack (end-to-end fine-tune, BASELINE config 5:
+// tf.gradients through conv1a..conv5b of feature_extration.prototxt:22-342, base.py:278-281).
+//
+// Per layer i, from conv5b down:
+//   dYpre[i]  gradient w.r.t. the conv output before pooling, in a halo-padded image of the conv's
+//             own resolution (so dgrad is the forward implicit GEMM again and wgrad gathers rows of it)
+//   wgrad     dW[i] += im2col(act[i])^T x dYpre[i]                       (wgrad.hip.h, transposing LDS reads)
+//   dgrad     d act[i] = dYpre[i] (*) rot180(W[i]) with in/out swapped   (igemm.hip.h, packed once per set_weights)
+//   unpool    pooled layer below: route each pooled gradient to the window member the forward epilogue
+//             recorded as arg-max, gated by ReLU (output > 0); un-pooled layer below: the ReLU gate is
+//             fused into the dgrad epilogue (EpiStoreMask).
+// Bias gradients are column sums of dYpre[i] (fused into unpool where there is one).
+#include <algorithm>
+
+#include "rgp_c3d_plan.h"
+#include "wgrad.hip.h"
+
+using namespace rgp;
+
+namespace {
+
+inline bool pooled(int i) { return kLayers[i].pd * kLayers[i].ph > 1; }
+
+// d(conv5b rows) -> dYpre[7] [n][4][9][9][512]: ReLU gate from the forward rows, layout change.
+// src_features != 0: src is [n][1024][7][7] with channel c*2+d (gaze_rnn.py:494-497); else [n*49][d*512+c].
+template <typename T>
+__global__ __launch_bounds__(256) void rows_grad_kernel(const float* __restrict__ src, int src_features, const T* __restrict__ fwd_rows,
+                                                        T* __restrict__ dypre, long long img_stride, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % 512);
+    const int d = (int)((i / 512) % 2);
+    const int pos = (int)((i / 1024) % 49);
+    const long long n = i / (1024 * 49);
+    const float g = src_features ? src[(n * 1024 + c * 2 + d) * 49 + pos] : src[(n * 49 + pos) * 1024 + d * 512 + c];
+    const bool on = Elem<T>::from(fwd_rows[(n * 49 + pos) * 1024 + d * 512 + c]) > 0.f;
+    const int y = pos / 7, x = pos % 7;
+    dypre[n * img_stride + (((long long)(d + 1) * 9 + y + 1) * 9 + x + 1) * 512 + c] = Elem<T>::to(on ? g : 0.f);
+  }
+}
+
+// Pooled layer: scatter dYp [n][PR][C] into dYpre through the recorded arg-max, gate by the pooled
+// forward output y > 0, and accumulate the bias gradient.  Thread = (row lane, 8-channel group).
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_kernel(const T* __restrict__ dyp, const unsigned char* __restrict__ amax,
+                                                     const T* __restrict__ y, const int* __restrict__ y_tab, long long y_img_stride,
+                                                     T* __restrict__ dypre, const int* __restrict__ win_tab,
+                                                     const int* __restrict__ q_off, long long dypre_stride, int PR, int C, int P,
+                                                     long long rows_total, float* __restrict__ db) {
+  const int CG = C / 8;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RL = 256 / CG;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long r = (long long)blockIdx.x * RL + rl; r < rows_total; r += (long long)gridDim.x * RL) {
+    const long long img = r / PR;
+    const int pr = (int)(r - img * PR);
+    float g[8];
+    unsigned code[8];
+    const T* gp = dyp + r * C + cg * 8;
+    const T* yp = y + img * y_img_stride + y_tab[pr] + cg * 8;
+    const unsigned char* ap = amax + r * C + cg * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool on = Elem<T>::from(yp[k]) > 0.f;
+      g[k] = on ? Elem<T>::from(gp[k]) : 0.f;
+      code[k] = ap[k];
+      bsum[k] += g[k];
+    }
+    T* base = dypre + img * dypre_stride + win_tab[pr] + cg * 8;
+    for (int q = 0; q < P; ++q) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = code[k] == (unsigned)q ? g[k] : 0.f;
+      store8<T>(base + q_off[q], v, 8);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (bsum[k] != 0.f) atomicAdd(db + cg * 8 + k, bsum[k]);
+}
+
+// Bias gradient of an un-pooled layer: column sums over the interior rows of dYpre.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ buf, const int* __restrict__ tab, long long img_stride,
+                                                     int Mw, int C, long long rows_total, float* __restrict__ db) {
+  const int CG = C / 8;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RL = 256 / CG;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long r = (long long)blockIdx.x * RL + rl; r < rows_total; r += (long long)gridDim.x * RL) {
+    const long long img = r / Mw;
+    const int ml = (int)(r - img * Mw);
+    const T* p = buf + img * img_stride + tab[ml] + cg * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bsum[k] += Elem<T>::from(p[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (bsum[k] != 0.f) atomicAdd(db + cg * 8 + k, bsum[k]);
+}
+
+// conv1a: packed K order ((kz,ky) tap, kx 0..3, c 0..3) -> DHWIO [3,3,3,3,64], accumulated
+__global__ void conv1a_unpack_grad_kernel(const float* __restrict__ dw1, float* __restrict__ grad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 27*3*64
+  if (i >= 27 * 3 * 64) return;
+  const int n = i % 64, c = (i / 64) % 3, tap = i / 192;
+  const int kx = tap % 3, t2 = tap / 3;                  // t2 = kz*3+ky
+  grad[i] += dw1[(long long)(t2 * 16 + kx * 4 + c) * 64 + n];
+}
+
+template <typename T, int G>
+int launch_wgrad(const WgradParams& p, hipStream_t s) {
+  auto kern = wgrad_kernel<T, G>;
+  constexpr int smem = WgradSmem<T>::BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + 127) / 128;
+  const long long total_steps = (p.M + 31) / 32;
+  long long splits = std::max<long long>(1, 1024 / (n_kt * n_nt));
+  splits = std::min(splits, total_steps);
+  WgradParams q = p;
+  q.steps_per_split = (int)((total_steps + splits - 1) / splits);
+  splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
+  kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+template <typename T>
+int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, float* grads, hipStream_t s) {
+  char* ws = c->ws;
+  const int n = c->last_n;
+  constexpr int G0 = sizeof(T) == 2 ? 4 : 2;
+  auto blocks_for = [](long long items, int per_block) { return (int)std::min<long long>((items + per_block - 1) / per_block, 4096); };
+  {  // conv5b: external gradient -> dYpre[7], bias gradient
+    const long long total = (long long)n * 49 * 1024;
+    rows_grad_kernel<T><<<blocks_for(total, 256), 256, 0, s>>>(d_features ? d_features : d_rows, d_features != nullptr,
+                                                              (const T*)(ws + c->act_off[8]), (T*)(ws + c->B[7].dypre_off),
+                                                              c->B[7].dypre_stride, total);
+    RGP_HIP(hipGetLastError());
+  }
+  for (int i = 7; i >= 0; --i) {
+    const C3dLayerSpec& l = kLayers[i];
+    const C3dBwdLayer& b = c->B[i];
+    const int Mw = l.D * l.H * l.H;
+    if (!pooled(i)) {  // bias gradient (pooled layers: done by unpool below)
+      const long long rows = (long long)n * Mw;
+      colsum_kernel<T><<<blocks_for(rows, 256 / (l.cout / 8) * 16), 256, 0, s>>>(
+          (const T*)(ws + b.dypre_off), (const int*)(ws + b.y_tab_off), b.dypre_stride, Mw, l.cout, rows, grads + b.grad_b);
+      RGP_HIP(hipGetLastError());
+    }
+    {  // filter gradient
+      WgradParams p;
+      p.X = ws + c->act_off[i];
+      p.dY = ws + b.dypre_off;
+      p.x_tab = (const int*)(ws + b.x_tab_off);
+      p.y_tab = (const int*)(ws + b.y_tab_off);
+      p.koff = (const int*)(ws + c->L[i].koff_off);
+      p.x_img_stride = c->act_stride[i];
+      p.y_img_stride = b.dypre_stride;
+      p.M = (long long)n * Mw;
+      p.Mw = Mw;
+      p.N = l.cout;
+      p.nk = c->L[i].nk;
+      p.ldw = l.cout;
+      p.steps_per_split = 0;
+      if (i == 0) {
+        p.dW = (float*)(ws + c->dw1_off);
+        RGP_HIP(hipMemsetAsync(p.dW, 0, (size_t)p.nk * Elem<T>::BKE * 64 * 4, s));
+        RGP_TRY((launch_wgrad<T, G0>(p, s)));
+        conv1a_unpack_grad_kernel<<<(27 * 3 * 64 + 255) / 256, 256, 0, s>>>(p.dW, grads + b.grad_w);
+        RGP_HIP(hipGetLastError());
+      } else {
+        p.dW = grads + b.grad_w;
+        RGP_TRY((launch_wgrad<T, 1>(p, s)));
+      }
+    }
+    if (i == 0) break;
+    // gradient w.r.t. the layer input = pooled (or plain) output of layer i-1
+    const C3dBwdLayer& lo = c->B[i - 1];
+    IgemmParams p = make_params(b.dg, ws + b.dypre_off, ws, n);
+    if (pooled(i - 1)) {
+      EpiParams e = make_epi(b.dg, ws + c->dyp_off, ws);
+      RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+      const C3dLayerSpec& ll = kLayers[i - 1];
+      const int PR = (ll.D / ll.pd) * (ll.H / ll.ph) * (ll.H / ll.ph);
+      const long long rows = (long long)n * PR;
+      unpool_kernel<T><<<blocks_for(rows, 256 / (ll.cout / 8) * 8), 256, 0, s>>>(
+          (const T*)(ws + c->dyp_off), (const unsigned char*)(ws + lo.argmax_off), (const T*)(ws + c->act_off[i]),
+          (const int*)(ws + c->unpad_off[i - 1]), c->act_stride[i], (T*)(ws + lo.dypre_off), (const int*)(ws + lo.win_tab_off),
+          (const int*)(ws + lo.q_off_off), lo.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, rows, grads + lo.grad_b);
+      RGP_HIP(hipGetLastError());
+    } else {
+      EpiParams e = make_epi(b.dg, ws + lo.dypre_off, ws);
+      e.mask = ws + c->act_off[i];
+      RGP_TRY((launch_igemm<T, 1, 1, EpiStoreMask<T>>(p, e, s)));
+    }
+  }
+  return RGP_OK;
+}
+
+}  // namespace
+
+int c3d_bwd_plan(rgp_c3d* c, Arena& a) {
+  const int dtype = c->dtype, es = esize(dtype);
+  bool ok = true;
+  size_t dyp_elems = 0, goff = 0;
+  for (int i = 0; i < 8; ++i) {
+    const C3dLayerSpec& l = kLayers[i];
+    C3dBwdLayer& b = c->B[i];
+    const int D = l.D, H = l.H, W = l.H, Hp = H + 2, Wp = W + 2, Co = l.cout;
+    const int Cx = i == 0 ? 4 : l.cin, Wpx = i == 0 ? W + 4 : W + 2;
+    b.dypre_stride = (long long)(D + 2) * Hp * Wp * Co;
+    for (int z = 0; z < D; ++z) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+      b.x_tab.push_back(((z * Hp + y) * Wpx + x) * Cx);
+      b.y_tab.push_back((((z + 1) * Hp + y + 1) * Wp + x + 1) * Co);
+    }
+    if (pooled(i)) {
+      const int Do = D / l.pd, Ho = H / l.ph, Wo = W / l.ph;
+      for (int zo = 0; zo < Do; ++zo) for (int yo = 0; yo < Ho; ++yo) for (int xo = 0; xo < Wo; ++xo)
+        b.win_tab.push_back((((zo * l.pd + 1) * Hp + yo * l.ph + 1) * Wp + xo * l.ph + 1) * Co);
+      for (int dz = 0; dz < l.pd; ++dz) for (int dy = 0; dy < l.ph; ++dy) for (int dx = 0; dx < l.ph; ++dx)
+        b.q_off.push_back(((dz * Hp + dy) * Wp + dx) * Co);
+      b.argmax_off = a.take((size_t)c->max_windows * Do * Ho * Wo * Co);
+      dyp_elems = std::max(dyp_elems, (size_t)Do * Ho * Wo * Co);
+    }
+    if (i >= 1) {
+      ConvDesc& d = b.dg;
+      d.Mw = D * H * W;
+      d.N = l.cin;
+      d.in_img_stride = b.dypre_stride;
+      std::vector<int> tapoff, fidx;
+      for (int z = 0; z < D; ++z) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) d.in_tab.push_back(((z * Hp + y) * Wp + x) * Co);
+      for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+        tapoff.push_back(((kz * Hp + ky) * Wp + kx) * Co);
+        fidx.push_back(26 - ((kz * 3 + ky) * 3 + kx));        // rot180
+      }
+      ok &= build_k_schedule(d, tapoff, fidx, Co, dtype);
+      d.s_tap = (long long)l.cin * l.cout; d.s_n = l.cout; d.s_c = 1;    // W[tap][n = cin][c = cout]
+      if (pooled(i - 1)) {
+        d.out_img_stride = (long long)d.Mw * l.cin;
+        for (int m = 0; m < d.Mw; ++m) d.out_tab.push_back(m * l.cin);
+      } else {
+        d.out_img_stride = c->B[i - 1].dypre_stride;
+        d.out_tab = c->B[i - 1].y_tab;
+      }
+      d.reserve(a, dtype);
+    }
+    b.x_tab_off = a.take(b.x_tab.size() * 4);
+    b.y_tab_off = a.take(b.y_tab.size() * 4);
+    b.win_tab_off = a.take(b.win_tab.size() * 4 + 4);
+    b.q_off_off = a.take(b.q_off.size() * 4 + 4);
+    b.dypre_off = a.take((size_t)c->max_windows * b.dypre_stride * es);
+    b.grad_w = goff; goff += (size_t)27 * l.cin * l.cout;
+    b.grad_b = goff; goff += l.cout;
+  }
+  c->n_params = goff;
+  c->dyp_off = a.take((size_t)c->max_windows * dyp_elems * es);
+  c->dw1_off = a.take((size_t)c->L[0].nk * bke(dtype) * 64 * 4);
+  if (!ok) return set_err(RGP_EINVAL, "rgp_c3d_create: backward K schedule failed");
+  return RGP_OK;
+}
+
+int c3d_bwd_upload(rgp_c3d* c, hipStream_t s) {
+  auto up = [&](const std::vector<int>& t, size_t off) -> int {
+    if (!t.empty()) RGP_HIP(hipMemcpyAsync(c->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
+    return RGP_OK;
+  };
+  for (int i = 0; i < 8; ++i) {
+    C3dBwdLayer& b = c->B[i];
+    if (i >= 1) RGP_TRY(upload_desc(b.dg, c->ws, s));
+    RGP_TRY(up(b.x_tab, b.x_tab_off)); RGP_TRY(up(b.y_tab, b.y_tab_off));
+    RGP_TRY(up(b.win_tab, b.win_tab_off)); RGP_TRY(up(b.q_off, b.q_off_off));
+  }
+  return RGP_OK;
+}
+
+int c3d_bwd_pack(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
+  for (int i = 1; i < 8; ++i) {
+    const ConvDesc& d = c->B[i].dg;
+    RGP_HIP(hipMemsetAsync(c->ws + d.w_off, 0, d.w_bytes(c->dtype), s));
+    if (c->dtype == RGP_BF16) RGP_TRY(pack_filter<bf16_t>(d, w->w[i], c->ws, kLayers[i].cin, 0, s));
+    else RGP_TRY(pack_filter<float>(d, w->w[i], c->ws, kLayers[i].cin, 0, s));
+  }
+  return RGP_OK;
+}
+
+extern "C" {
+
+size_t rgp_c3d_param_elems(const rgp_c3d_t* c) {
+  if (!c) return 0;
+  size_t n = 0;
+  for (int i = 0; i < 8; ++i) n += (size_t)27 * kLayers[i].cin * kLayers[i].cout + kLayers[i].cout;
+  return n;
+}
+
+size_t rgp_c3d_param_offset(const rgp_c3d_t* c, int layer, int is_bias) {
+  size_t off = 0;
+  for (int i = 0; i < 8 && i <= layer; ++i) {
+    if (i == layer) return off + (is_bias ? (size_t)27 * kLayers[i].cin * kLayers[i].cout : 0);
+    off += (size_t)27 * kLayers[i].cin * kLayers[i].cout + kLayers[i].cout;
+  }
+  return off;
+}
+
+int rgp_c3d_read_grad_image(rgp_c3d_t* c, int layer, int n_windows, float* dst, rgp_stream_t stream) {
+  RGP_REQUIRE(c && c->ws && c->save && dst && layer >= 0 && layer <= 7 && n_windows > 0 && n_windows <= c->max_windows,
+              "rgp_c3d_read_grad_image: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const C3dBwdLayer& b = c->B[layer];
+  const int rows = (int)b.y_tab.size(), C = kLayers[layer].cout;
+  const long long total = (long long)n_windows * rows * C;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  const int* tab = (const int*)(c->ws + b.y_tab_off);
+  if (c->dtype == RGP_BF16)
+    unpad_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)(c->ws + b.dypre_off), dst, tab, rows, C, b.dypre_stride, total);
+  else
+    unpad_kernel<float><<<blocks, 256, 0, s>>>((const float*)(c->ws + b.dypre_off), dst, tab, rows, C, b.dypre_stride, total);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+int rgp_c3d_backward(rgp_c3d_t* c, const float* d_features, const float* d_rows, int n_windows, float* grads,
+                     rgp_stream_t stream) {
+  RGP_REQUIRE(c && grads && (d_features != nullptr) != (d_rows != nullptr),
+              "rgp_c3d_backward: need grads and exactly one of d_features / d_rows");
+  if (!c->save) return set_err(RGP_ESTATE, "rgp_c3d_backward: plan was not created with save_for_backward");
+  if (!c->ws || !c->weights_set) return set_err(RGP_ESTATE, "rgp_c3d_backward: workspace/weights not set");
+  if (n_windows != c->last_n || n_windows <= 0)
+    return set_err(RGP_ESTATE, "rgp_c3d_backward: n_windows %d != windows of the last forward chunk (%d); forward at most "
+                   "max_windows windows, then call backward", n_windows, c->last_n);
+  hipStream_t s = (hipStream_t)stream;
+  return c->dtype == RGP_BF16 ? backward_impl<bf16_t>(c, d_features, d_rows, grads, s)
+                              : backward_impl<float>(c, d_features, d_rows, grads, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Plan object of the C3D conv stack, shared by the forward (rgp_c3d.hip) and backward
+// (rgp_c3d_bwd.hip) translation units.
+#pragma once
+#include <vector>
+
+#include "rgp_host.h"
+
+struct C3dLayerSpec {
+  int cin, cout, D, H, pd, ph;  // input extent (W == H), pooling window (depth, spatial); 1 = none
+};
+// conv1a..conv5b, feature_extration.prototxt:22-342
+static const C3dLayerSpec kLayers[8] = {
+    {3, 64, 16, 112, 1, 2},  {64, 128, 16, 56, 2, 2}, {128, 256, 8, 28, 1, 1}, {256, 256, 8, 28, 2, 2},
+    {256, 512, 4, 14, 1, 1}, {512, 512, 4, 14, 2, 2}, {512, 512, 2, 7, 1, 1},  {512, 512, 2, 7, 1, 1},
+};
+
+// Box decomposition of one layer for conv3d_halo_kernel (tables live in the workspace).
+struct HaloDesc {
+  bool used = false;
+  int BZ = 0, BY = 0, BX = 0, HP8 = 0, nbx = 0, nby = 0, nbz = 0, bufs = 1;
+  int box_in[3] = {0, 0, 0}, box_out[3] = {0, 0, 0};
+  std::vector<int> goff, row_hp, tap_shift, out_tab;
+  size_t goff_off = 0, row_hp_off = 0, tap_shift_off = 0, out_tab_off = 0;
+  size_t smem = 0;
+};
+
+// Backward state of one layer (present when the plan was created with save_for_backward).
+struct C3dBwdLayer {
+  rgp::ConvDesc dg;                 // dgrad implicit GEMM over dYpre with the rotated, in/out-swapped filter (layers 1..7)
+  std::vector<int> x_tab, y_tab;    // wgrad row tables: window origin in act[i] / position in dYpre[i], natural (z,y,x) order
+  std::vector<int> win_tab;         // pooled layers: origin of each pooling window in dYpre[i]
+  std::vector<int> q_off;           // pooled layers: offset of window member q (dz,dy,dx order)
+  size_t x_tab_off = 0, y_tab_off = 0, win_tab_off = 0, q_off_off = 0;
+  size_t dypre_off = 0;             // [max_windows][D+2][H+2][W+2][Cout] operand dtype, halos zero
+  long long dypre_stride = 0;       // elements per window
+  size_t argmax_off = 0;            // pooled layers: [max_windows][Do*Ho*Wo][Cout] bytes
+  size_t grad_w = 0, grad_b = 0;    // element offsets into the flat fp32 gradient vector
+};
+
+struct rgp_c3d {
+  int max_windows = 0, dtype = RGP_BF16;
+  HaloDesc halo[8];
+  rgp::ConvDesc L[8];
+  size_t act_off[9] = {0};       // act[i] = halo-padded input of layer i; act[8] = conv5b rows
+  long long act_stride[9] = {0}; // elements per window
+  std::vector<int> unpad_tab[8];
+  size_t unpad_off[8] = {0};
+  size_t starts_off = 0;         // int32 [max_windows] first-frame index of each window (frames entry)
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  bool weights_set = false;
+  const float* bias[8] = {nullptr};
+  rgp::StageProfiler prof;
+  // ---- backward ----
+  bool save = false;
+  C3dBwdLayer B[8];
+  size_t dyp_off = 0;            // dense pooled-gradient scratch (largest pooled layer)
+  size_t dw1_off = 0;            // conv1a filter gradient in its packed K order, fp32
+  size_t n_params = 0;           // 27 655 936 = sum of w[i] + b[i]
+  int last_n = 0;                // windows of the last forward (what backward differentiates)
+};
+
+// rgp_c3d_bwd.hip
+int c3d_bwd_plan(rgp_c3d* c, rgp::Arena& a);                                      // tables + workspace layout
+int c3d_bwd_upload(rgp_c3d* c, hipStream_t s);
+int c3d_bwd_pack(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s);            // rotated dgrad filters

@@ -1,0 +1,231 @@
+// Filter-gradient implicit GEMM for gfx950 (the wgrad half of tf.gradients through a conv layer,
+// base.py:278-281 applied to the C3D stack of feature_extration.prototxt:22-342):
+//
+//   dW[k][n] += sum_m  X[rowbase_x(m) + koff(k)] * dY[rowbase_y(m) + n]
+//
+// i.e. (im2col)^T x dY with the REDUCTION over the output rows m.  Both operands are stored with the
+// reduction index strided in memory (activations are channels-last), the opposite of what an MFMA
+// fragment wants, so:
+//  * row tiles [32 rows][128 B] of X (per K-chunk) and [32 rows][128 cols] of dY are staged by LDS-DMA
+//    exactly as they lie in HBM (full 128/256-B lines, no transposing gather),
+//  * bf16 fragments are read with ds_read_b64_tr_b16, the gfx950 transposing LDS read: a 16-lane group
+//    fetches a 4-row x 16-column block and each lane receives one column = 4 consecutive reduction
+//    indices of its channel; two reads make the 8-deep k-group of v_mfma_f32_16x16x32_bf16,
+//  * 32-byte segments are XOR-swizzled per row (on the DMA source side, the LDS image is lane-linear)
+//    so the 8 rows a 32-lane half touches fall in 8 different bank groups,
+//  * fp32 uses v_mfma_f32_16x16x4_f32 whose fragments are single dwords: plain ds_read_b32.
+// Block tile: 4 K-chunks (4 x 64 bf16 / 4 x 32 fp32 filter rows) x 128 output channels, 8 waves as
+// 4 (chunk) x 2 (64 columns); the reduction is split over blockIdx.y and combined with fp32 atomics.
+// 3-stage DMA ring, one raw barrier per 32-row step, counted vmcnt.
+#pragma once
+#include "igemm.hip.h"
+
+namespace rgp {
+
+struct WgradParams {
+  const void* X;           // layer input, halo-padded channels-last (operand dtype)
+  const void* dY;          // gradient w.r.t. the conv output before pooling, halo-padded (operand dtype);
+                           // its first 128*sizeof(T) bytes must be zero (they are: halo)
+  float* dW;               // [nk*BKE][ldw] fp32, accumulated with atomics
+  const int* x_tab;        // [Mw] element offset of row m's window origin inside one X image
+  const int* y_tab;        // [Mw] element offset of row m inside one dY image
+  const int* koff;         // [nk*G] element offset of each K (sub-)chunk
+  long long x_img_stride, y_img_stride;
+  long long M;             // rows = images * Mw
+  int Mw, N, nk, ldw;
+  int steps_per_split;     // 32-row steps per blockIdx.y
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct WgradSmem {
+  static constexpr int XB = 4 * 32 * 128;                    // 4 chunks x 32 rows x 128 B
+  static constexpr int YB = 32 * 128 * (int)sizeof(T);       // 32 rows x 128 columns
+  static constexpr int STAGE = XB + YB;
+  static constexpr int BYTES = 3 * STAGE;
+};
+
+// 16-byte-chunk XOR applied to row r of an X tile / a dY tile (bf16 only; see header comment)
+template <typename T> __device__ __forceinline__ int wg_swz_x(int r) {
+  return sizeof(T) == 2 ? 2 * (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) : 0;
+}
+template <typename T> __device__ __forceinline__ int wg_swz_y(int r) {
+  return sizeof(T) == 2 ? 2 * ((r & 3) | (((r >> 3) & 1) << 2)) : 0;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
+  constexpr int ESZ = sizeof(T);
+  constexpr int BKE = Elem<T>::BKE;               // filter rows per K-chunk (64 bf16, 32 fp32)
+  constexpr int CI = BKE / 16;                    // 16-row tiles per chunk
+  constexpr int NYL = ESZ == 2 ? 1 : 2;           // dY DMA instructions per thread and step
+  constexpr int YROWB = 128 * ESZ;                // bytes per dY tile row
+  constexpr int PER_STEP = 2 + NYL;               // DMA instructions per thread and step
+  using S = WgradSmem<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+  const int n_kt = (p.nk + 3) / 4;
+  const int kt = blockIdx.x % n_kt, nt = blockIdx.x / n_kt;
+  const int n0 = nt * 128;
+  const long long m_begin = (long long)blockIdx.y * p.steps_per_split * 32;
+  long long m_end = m_begin + (long long)p.steps_per_split * 32;
+  if (m_end > p.M) m_end = p.M;
+  if (m_begin >= m_end) return;
+  const int nsteps = (int)((m_end - m_begin + 31) / 32);
+
+  // ---- DMA source bookkeeping: each thread owns one X row (2 chunks of it) and NYL dY rows ----
+  const int xr = 8 * (wave & 3) + (lane >> 3);              // tile row of this thread's X loads
+  const int xc = (lane & 7) ^ wg_swz_x<T>(xr);              // logical 16-B chunk it fetches
+  const char* xsrc_k[2];                                    // chunk-dependent part (koff), fixed per block
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    int kc = kt * 4 + (wave >> 2) + 2 * u;
+    if (kc >= p.nk) kc = p.nk - 1;                          // duplicate work, never stored
+    const int elems_per_sub = BKE / G, ce = xc * (16 / ESZ);
+    const int sub = ce / elems_per_sub, off = ce - sub * elems_per_sub;
+    xsrc_k[u] = (const char*)p.X + ((long long)p.koff[kc * G + sub] + off) * ESZ;
+  }
+  int yr[NYL], yc[NYL];
+#pragma unroll
+  for (int u = 0; u < NYL; ++u) {
+    yr[u] = ESZ == 2 ? (tid >> 4) : ((tid >> 5) + 16 * u);
+    const int phys = ESZ == 2 ? (tid & 15) : (tid & 31);
+    yc[u] = phys ^ wg_swz_y<T>(yr[u]);
+  }
+  // running (image, row-in-image) of each owned row
+  int x_img, x_ml, y_img[NYL], y_ml[NYL];
+  {
+    const long long m = m_begin + xr;
+    x_img = (int)(m / p.Mw);
+    x_ml = (int)(m - (long long)x_img * p.Mw);
+#pragma unroll
+    for (int u = 0; u < NYL; ++u) {
+      const long long my = m_begin + yr[u];
+      y_img[u] = (int)(my / p.Mw);
+      y_ml[u] = (int)(my - (long long)y_img[u] * p.Mw);
+    }
+  }
+  int x_step = 0, y_step = 0;     // steps already issued
+
+  auto issue = [&](int buf) {
+    char* xb = smem + buf * S::STAGE;
+    char* yb = xb + S::XB;
+    {
+      const bool ok = m_begin + (long long)x_step * 32 + xr < m_end;
+      const long long base = ok ? ((long long)x_img * p.x_img_stride + p.x_tab[x_ml]) * ESZ : 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const char* src = ok ? xsrc_k[u] + base : (const char*)p.X;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xb + ((wave >> 2) + 2 * u) * 4096 + (wave & 3) * 1024),
+                                         16, 0, 0);
+      }
+      x_ml += 32;
+      while (x_ml >= p.Mw) { x_ml -= p.Mw; ++x_img; }
+      ++x_step;
+    }
+#pragma unroll
+    for (int u = 0; u < NYL; ++u) {
+      const bool ok = m_begin + (long long)y_step * 32 + yr[u] < m_end;
+      const char* src = (const char*)p.dY;
+      if (ok) src += (((long long)y_img[u] * p.y_img_stride + p.y_tab[y_ml[u]]) + n0) * ESZ + yc[u] * 16;
+      else src += (yc[u] & 7) * 16;                                        // zeros (halo)
+      const int ldsoff = ESZ == 2 ? wave * 1024 : (16 * u + 2 * wave) * 512;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(yb + ldsoff), 16, 0, 0);
+      y_ml[u] += 32;
+      while (y_ml[u] >= p.Mw) { y_ml[u] -= p.Mw; ++y_img[u]; }
+    }
+    ++y_step;
+  };
+
+  f32x4 acc[CI][4];
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fcol = lane & 15, g = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* xb = smem + buf * S::STAGE + wk * 4096;
+    const char* yb = smem + buf * S::STAGE + S::XB;
+    if constexpr (ESZ == 2) {
+      const int q = fcol >> 2, pp = fcol & 3;
+      const int row = 8 * g + q;                                 // rows row and row+4 share the swizzle
+      const int sx = (wg_swz_x<T>(row) >> 1), sy = (wg_swz_y<T>(row) >> 1);
+      f32x4 a[CI], b[4];
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const char* ad = xb + row * 128 + ((i ^ sx) * 32) + pp * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ad);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 512));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[i] = __builtin_bit_cast(f32x4, v);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const char* bd = yb + row * 256 + (((wn * 4 + j) ^ sy) * 32) + pp * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)bd);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bd + 1024));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        b[j] = __builtin_bit_cast(f32x4, v);
+      }
+#pragma unroll
+      for (int i = 0; i < CI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int row = 4 * s + g;
+        float a[CI], b[4];
+#pragma unroll
+        for (int i = 0; i < CI; ++i) a[i] = *(const float*)(xb + row * 128 + (i * 16 + fcol) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *(const float*)(yb + row * 512 + ((wn * 4 + j) * 16 + fcol) * 4);
+#pragma unroll
+        for (int i = 0; i < CI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- 3-stage ring: steps s+1 and s+2 are in flight while step s is consumed.  Steps beyond the
+  // block's range are issued too (they fetch zeros), so the vmcnt arithmetic is uniform. ----
+  issue(0);
+  issue(1);
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < nsteps; ++s) {
+    if (PER_STEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
+    issue((s + 2) % 3);
+    compute(s % 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: D[row = 4*(lane>>4)+r (filter row), col = lane&15 (output channel)] ----
+  const int kc = kt * 4 + wk;
+  if (kc < p.nk) {
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (wn * 4 + j) * 16 + fcol;
+        if (n < p.N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long k = (long long)kc * BKE + i * 16 + g * 4 + r;
+            atomicAdd(p.dW + k * p.ldw + n, acc[i][j][r]);
+          }
+        }
+      }
+  }
+}
+
+}  // namespace rgp

@@ -18,6 +18,8 @@ GRCN_PARAM_TO_FIELD = {   # reference TF variable name -> rgp_grcn_weights field
     'weight1': 'up_weight1', 'weight2': 'up_weight2', 'weight3': 'up_weight3', 'out_W': 'out_W', 'out_b': 'out_b',
 }
 C3D_LAYER_NAMES = ('conv1a', 'conv2a', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5a', 'conv5b')
+C3D_EXTENTS = ((16, 112), (16, 56), (8, 28), (8, 28), (4, 14), (4, 14), (2, 7), (2, 7))     # conv output D, H (= W)
+C3D_CHANNELS = ((3, 64), (64, 128), (128, 256), (256, 256), (256, 512), (512, 512), (512, 512), (512, 512))
 
 
 def _stream_ptr(device):
@@ -349,37 +351,79 @@ class CascadeEngine(object):
 class C3DEngine(object):
     """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
 
-    def __init__(self, max_windows, dtype='bf16', device='cuda:0'):
+    def __init__(self, max_windows, dtype='bf16', device='cuda:0', save_for_backward=False):
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.max_windows = int(max_windows)
         self.dtype = dtype
+        self.save_for_backward = bool(save_for_backward)
         self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.rgp_c3d_create(ctypes.byref(self._h), self.max_windows, _lib.DTYPES[dtype]))
+            _lib.check(self.lib.rgp_c3d_create_ex(ctypes.byref(self._h), self.max_windows, _lib.DTYPES[dtype],
+                                                  int(self.save_for_backward)))
             nbytes = self.lib.rgp_c3d_workspace_bytes(self._h)
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_c3d_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
-        self.weights = None
+        # fp32 master parameters in one flat vector, layout w[0], b[0], w[1], b[1], ... (= rgp_c3d_backward's grads)
+        n = self.lib.rgp_c3d_param_elems(self._h)
+        self.flat_params = torch.zeros(n, device=self.device)
+        self.flat_grads = torch.zeros(n, device=self.device) if self.save_for_backward else None
+        self.adam_m = self.adam_v = None
+        self.weights = {}
+        for i, name in enumerate(C3D_LAYER_NAMES):
+            cin, cout = C3D_CHANNELS[i]
+            ow, ob = self.lib.rgp_c3d_param_offset(self._h, i, 0), self.lib.rgp_c3d_param_offset(self._h, i, 1)
+            self.weights[name + '_w'] = self.flat_params[ow:ow + 27 * cin * cout].view(3, 3, 3, cin, cout)
+            self.weights[name + '_b'] = self.flat_params[ob:ob + cout]
+        self.weights_set = False
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
         if h:
             self.lib.rgp_c3d_destroy(h)
 
+    def grad_views(self):
+        """{name: view into flat_grads} with the shapes of the parameters."""
+        out = {}
+        for i, name in enumerate(C3D_LAYER_NAMES):
+            cin, cout = C3D_CHANNELS[i]
+            ow, ob = self.lib.rgp_c3d_param_offset(self._h, i, 0), self.lib.rgp_c3d_param_offset(self._h, i, 1)
+            out[name + '_w'] = self.flat_grads[ow:ow + 27 * cin * cout].view(3, 3, 3, cin, cout)
+            out[name + '_b'] = self.flat_grads[ob:ob + cout]
+        return out
+
     def set_weights(self, params):
-        """params: {'conv1a_w': [3,3,3,Cin,Cout], 'conv1a_b': [Cout], ...} fp32."""
-        w = {}
+        """params: {'conv1a_w': [3,3,3,Cin,Cout], 'conv1a_b': [Cout], ...} fp32 -> master copy + packed operands."""
+        for name in C3D_LAYER_NAMES:
+            for suffix in ('_w', '_b'):
+                self.weights[name + suffix].copy_(_as_dev_f32(params[name + suffix], self.device).reshape(
+                    self.weights[name + suffix].shape))
+        self.repack()
+
+    def repack(self):
+        """Re-derive the packed (and, for training, rotated) operand filters from the master parameters."""
         st = _lib.C3DWeights()
         for i, name in enumerate(C3D_LAYER_NAMES):
-            w[name + '_w'] = _as_dev_f32(params[name + '_w'], self.device)
-            w[name + '_b'] = _as_dev_f32(params[name + '_b'], self.device)
-            st.w[i] = w[name + '_w'].data_ptr()
-            st.b[i] = w[name + '_b'].data_ptr()
-        self.weights = w
+            st.w[i] = self.weights[name + '_w'].data_ptr()
+            st.b[i] = self.weights[name + '_b'].data_ptr()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_c3d_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+        self.weights_set = True
+
+    def backward(self, d_features=None, d_rows=None, zero_grads=True):
+        """Gradient of the last forward (<= max_windows windows) w.r.t. every conv filter and bias, given the
+        gradient w.r.t. conv5b as d_features [n,1024,7,7] or d_rows [n*49,1024] (fp32); fills flat_grads."""
+        assert self.save_for_backward, 'create the engine with save_for_backward=True'
+        g = d_features if d_features is not None else d_rows
+        assert (d_features is None) != (d_rows is None) and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()
+        n = g.shape[0] if d_features is not None else g.shape[0] // 49
+        if zero_grads:
+            self.flat_grads.zero_()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_backward(self._h, _ptr(d_features), _ptr(d_rows), n, _ptr(self.flat_grads),
+                                                 _stream_ptr(self.device)))
+        return self.flat_grads
 
     def forward(self, video, want_features=True, want_rows=False, out_rows=None):
         """video [n,16,112,112,3] fp32 device tensor -> (features [n,1024,7,7] fp32, rows)."""
@@ -393,6 +437,14 @@ class C3DEngine(object):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_c3d_forward(self._h, _ptr(video), n, _ptr(feats), _ptr(rows), _stream_ptr(self.device)))
         return feats, rows
+
+    def read_grad_image(self, layer, n_windows):
+        """After backward(): d loss / d (conv output of `layer` before ReLU and pooling), [n,D,H,W,Cout] fp32."""
+        d, h = C3D_EXTENTS[layer]
+        out = torch.empty(n_windows, d, h, h, C3D_CHANNELS[layer][1], device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_c3d_read_grad_image(self._h, layer, n_windows, _ptr(out), _stream_ptr(self.device)))
+        return out
 
     def _frames_args(self, frames, window_starts, mean_cube):
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4

@@ -1,0 +1,163 @@
+"""GPU parity: backward of the C3D conv stack (rgp_c3d_backward: wgrad with transposing LDS reads, dgrad,
+arg-max unpooling) against torch's CPU gradient operators (oracle side).
+
+The stack is piecewise linear (ReLU gates, max-pool routing).  A bf16 forward flips the gates of near-zero
+activations, and even the fp32 path resolves an occasional near-tie of a pooling window differently from a
+CPU run, so an end-to-end comparison with autograd measures those flips, not the kernels.  The parity
+test therefore checks every operator LOCALLY on the operands the kernels really consumed (read back from
+the device): filter and bias gradients, the input gradient through the ReLU gate, and the pooling
+routing (one member per window, a maximal one, carrying the gated pooled gradient).  The end-to-end
+autograd comparison is kept as an RMS-level check.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref
+from recurrent_gaze_prediction_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+NAMES = ('conv1a', 'conv2a', 'conv3a', 'conv3b', 'conv4a', 'conv4b', 'conv5a', 'conv5b')
+POOL = {name: pool for name, _, _, pool in torch_ref.C3D_LAYERS}
+# local operator checks: max-abs error relative to the reference's max-abs
+TOL_LOCAL = {'f32': 1e-4, 'bf16': 1.5e-2}
+# end-to-end vs autograd on the fp32 CPU graph: RMS error relative to RMS (see module docstring)
+TOL_E2E_RMS = {'f32': 3e-2, 'bf16': 0.5}
+
+
+def rel(a, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def rms_rel(a, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.sqrt(((np.asarray(a, np.float64) - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-30))
+
+
+@pytest.fixture(scope='module')
+def case():
+    p = syn.c3d_params(31)
+    rs = np.random.RandomState(32)
+    video = (rs.rand(2, 16, 112, 112, 3).astype(np.float32) - 0.5) * 2
+    g = rs.randn(2, 1024, 7, 7).astype(np.float32)
+    return p, video, g
+
+
+@pytest.fixture(scope='module')
+def autograd(case):
+    p, video, g = case
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    feat = torch_ref.c3d_forward(torch.tensor(video), tp)
+    (feat * torch.tensor(g)).sum().backward()
+    torch.set_num_threads(old)
+    return feat.detach().numpy(), {k: v.grad.numpy() for k, v in tp.items()}
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_c3d_backward_operators(gpu, case, autograd, dtype):
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, video, g = case
+    feat_ref, grads_ref = autograd
+    n = video.shape[0]
+    tol = TOL_LOCAL[dtype]
+    rnd = (lambda t: t.bfloat16().float()) if dtype == 'bf16' else (lambda t: t)     # operand rounding of the kernels
+    eng = C3DEngine(n, dtype=dtype, device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    feat, _ = eng.forward(torch.tensor(video, device=gpu))
+    assert rel(feat.cpu().numpy(), feat_ref) < (2e-5 if dtype == 'f32' else 3e-2)
+    eng.backward(d_features=torch.tensor(g, device=gpu))
+    grads = {k: v.cpu() for k, v in eng.grad_views().items()}
+    # operands as the device holds them
+    acts = [rnd(torch.tensor(video))] + [eng.read_layer(i, n).cpu().reshape(
+        (n,) + tuple(int(v) for v in (torch_ref_out_shape(i)))) for i in range(7)]
+    dys = [eng.read_grad_image(i, n).cpu() for i in range(8)]
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        # conv5b: external gradient gated by the forward output
+        f5 = feat.cpu().reshape(n, 512, 2, 7, 7).permute(0, 2, 3, 4, 1)
+        g5 = torch.tensor(g).reshape(n, 512, 2, 7, 7).permute(0, 2, 3, 4, 1)
+        assert rel(dys[7].numpy(), (rnd(g5) * (f5 > 0)).numpy()) < 1e-6
+        for i in range(7, -1, -1):
+            name = NAMES[i]
+            x, dy = ncdhw(acts[i]), ncdhw(dys[i])
+            w = rnd(torch.tensor(p[name + '_w'])).permute(4, 3, 0, 1, 2).contiguous()          # [Co,Ci,kd,kh,kw]
+            dw = torch.nn.grad.conv3d_weight(x, w.shape, dy, padding=1).permute(2, 3, 4, 1, 0)
+            assert rel(grads[name + '_w'].numpy(), dw.numpy()) < tol, ('wgrad', name)
+            assert rel(grads[name + '_b'].numpy(), dy.sum(dim=(0, 2, 3, 4)).numpy()) < tol, ('bias', name)
+            if i == 0:
+                break
+            dx = torch.nn.grad.conv3d_input(x.shape, w, dy, padding=1).permute(0, 2, 3, 4, 1)   # d loss / d act[i]
+            gated = dx * (acts[i] > 0)
+            lo = NAMES[i - 1]
+            if POOL[lo] is None:
+                assert rel(dys[i - 1].numpy(), gated.numpy()) < tol, ('dgrad', name)
+                continue
+            pd, ph = POOL[lo]
+            d = dys[i - 1]
+            nn_, D, H, W, C = d.shape
+            win = d.reshape(nn_, D // pd, pd, H // ph, ph, W // ph, ph, C).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(
+                nn_, D // pd, H // ph, W // ph, C, pd * ph * ph)
+            assert int(((win != 0).sum(-1) > 1).sum()) == 0, ('unpool: more than one member per window', lo)
+            assert rel(win.sum(-1).numpy(), gated.numpy()) < tol, ('dgrad+unpool', name)
+            # the routed member attains the window maximum of the conv output (ties within rounding)
+            wl = rnd(torch.tensor(p[lo + '_w'])).permute(4, 3, 0, 1, 2).contiguous()
+            z = F.conv3d(ncdhw(acts[i - 1]), wl, torch.tensor(p[lo + '_b']), padding=1).permute(0, 2, 3, 4, 1)
+            zw = z.reshape(nn_, D // pd, pd, H // ph, ph, W // ph, ph, C).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(win.shape)
+            chosen = (win != 0)
+            slack = zw.max(-1, keepdim=True).values - zw
+            worst = float((slack * chosen).max() / zw.abs().max())
+            assert worst < (1e-5 if dtype == 'f32' else 2e-2), ('unpool routing', lo, worst)
+    finally:
+        torch.set_num_threads(old)
+    # end-to-end against autograd of the fp32 CPU graph (RMS level, see module docstring)
+    errs = {k: rms_rel(grads[k].numpy(), grads_ref[k]) for k in grads_ref}
+    assert max(errs.values()) < TOL_E2E_RMS[dtype], errs
+    # d_rows entry (layout of the rows buffer: [n*49][d*512+c]) gives the same gradients
+    rows = torch.tensor(g, device=gpu).reshape(n, 512, 2, 49).permute(0, 3, 2, 1).reshape(n * 49, 1024).contiguous()
+    eng.forward(torch.tensor(video, device=gpu))
+    eng.backward(d_rows=rows)
+    again = {k: v.cpu().numpy() for k, v in eng.grad_views().items()}
+    assert all(rel(again[k], grads[k].numpy()) < 1e-4 for k in grads)      # fp32 atomics: order-dependent rounding only
+
+
+def torch_ref_out_shape(i):
+    """NDHWC extent of layer i's pooled output."""
+    d, h = {0: (16, 56), 1: (8, 28), 2: (8, 28), 3: (4, 14), 4: (4, 14), 5: (2, 7), 6: (2, 7)}[i]
+    return d, h, h, torch_ref.C3D_LAYERS[i][2]
+
+
+def test_training_forward_equals_inference_forward(gpu, case):
+    """Recording the arg-max must not change the forward output (bit-exact, bf16 path incl. the conv1a kernel)."""
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, video, _ = case
+    v = torch.tensor(video[:1], device=gpu)
+    a = C3DEngine(1, dtype='bf16', device=gpu)
+    a.set_weights(p)
+    b = C3DEngine(1, dtype='bf16', device=gpu, save_for_backward=True)
+    b.set_weights(p)
+    fa, fb = a.forward(v)[0], b.forward(v)[0]
+    assert torch.equal(fa, fb)
+
+
+def test_backward_requires_training_plan_and_matching_windows(gpu, case):
+    from recurrent_gaze_prediction_amd._lib import RgpError
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, video, g = case
+    eng = C3DEngine(2, dtype='bf16', device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    eng.forward(torch.tensor(video[:1], device=gpu))
+    with pytest.raises(RgpError):
+        eng.backward(d_features=torch.tensor(g, device=gpu))          # 2 windows of gradient, 1 forwarded
+    inf = C3DEngine(1, dtype='bf16', device=gpu)
+    inf.set_weights(p)
+    with pytest.raises(AssertionError):
+        inf.backward(d_features=torch.tensor(g[:1], device=gpu))
