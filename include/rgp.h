@@ -115,6 +115,11 @@ int rgp_softmax_xent_fwd(const float* logits, const float* labels, float* probs,
 int rgp_grcn_backward(rgp_grcn_t* plan, const float* logits, const float* probs, const float* labels,
                       const rgp_grcn_weights* grads, int loss_type, rgp_stream_t stream);
 
+/* After rgp_grcn_backward: the gradient w.r.t. the network input, d_rows [B*T*49, 1024] fp32 in the column
+ * order of the conv5b rows (d*512 + c) -- what rgp_c3d_backward takes when the conv stack is fine-tuned
+ * end to end (BASELINE config 5). */
+int rgp_grcn_backward_input(rgp_grcn_t* plan, float* d_rows, rgp_stream_t stream);
+
 /* tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients on one flat fp32 parameter
  * buffer (base.py:286-297; TF form: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), theta -= lr_t*m/(sqrt(v)+eps),
  * t = step+1).  workspace: 256 floats.  grad_norm_out (optional, device): the global norm.
@@ -122,6 +127,16 @@ int rgp_grcn_backward(rgp_grcn_t* plan, const float* logits, const float* probs,
 int rgp_adam_clip_step(float* params, const float* grads, float* m, float* v, long long n, float* workspace,
                        int step, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                        float* grad_norm_out, rgp_stream_t stream);
+
+/* The same step when the variables live in several flat buffers (conv stack + head, config 5): the clip
+ * norm is global over ALL of them (base.py:286-292).  rgp_global_sqnorm writes RGP_SQNORM_PARTIALS partial
+ * sums of squares of one buffer; rgp_adam_clip_step_ext applies the step to one buffer given the
+ * concatenated partials of all buffers. */
+#define RGP_SQNORM_PARTIALS 256
+int rgp_global_sqnorm(const float* grads, long long n, float* partials, rgp_stream_t stream);
+int rgp_adam_clip_step_ext(float* params, const float* grads, float* m, float* v, long long n, const float* partials,
+                           int n_partials, int step, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                           float* grad_norm_out, rgp_stream_t stream);
 
 /* Stage timing (HIP events recorded on the caller's stream around each stage launch
  * group; costs two hipEventRecord per stage).  Stages: 0 proj (incl. transpose),

@@ -16,6 +16,7 @@ import torch  # noqa: F401
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librgp_hip.so')
 
 RGP_F32, RGP_BF16 = 0, 1
+RGP_SQNORM_PARTIALS = 256          # include/rgp.h
 DTYPES = {'f32': RGP_F32, 'fp32': RGP_F32, 'float32': RGP_F32, 'bf16': RGP_BF16, 'bfloat16': RGP_BF16}
 
 c_void_p, c_int, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p
@@ -71,6 +72,7 @@ SIGNATURES = {
     'rgp_head_fwd': (c_int, [c_void_p, c_void_p, c_void_p]),
     'rgp_grcn_read_buffer': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
     'rgp_grcn_buffer_elems': (c_size_t, [c_void_p, c_char_p]),
+    'rgp_grcn_backward_input': (c_int, [c_void_p, c_void_p, c_void_p]),
     'rgp_softmax_xent_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'rgp_fcgru_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
     'rgp_fcgru_destroy': (c_int, [c_void_p]),
@@ -112,6 +114,10 @@ SIGNATURES = {
     'rgp_adam_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int,
                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                    c_void_p, c_void_p]),
+    'rgp_global_sqnorm': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    'rgp_adam_clip_step_ext': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       c_void_p, c_void_p]),
     'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
     'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),

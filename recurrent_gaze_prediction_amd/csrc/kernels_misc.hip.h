@@ -154,6 +154,15 @@ __global__ __launch_bounds__(256) void video_prep_kernel(const float* __restrict
   }
 }
 
+// conv5b rows [M][d*512+c] -> xt [M][c*2+d] (the layout nchw_to_rows_kernel produces from c3d_input)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_xt_kernel(const T* __restrict__ rows, T* __restrict__ xt, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ch = (int)(i & 1023);
+    xt[i] = rows[(i - ch) + (ch & 1) * 512 + (ch >> 1)];
+  }
+}
+
 // The VIDEO_DATA layer of the C3D prototxt (feature_extration.prototxt:3-21) on device: window w is the
 // 16 consecutive uint8 frames from starts[w]; each is resized to 128x171 (bilinear, half-pixel centres,
 // edge-clamped, rounded back to an 8-bit level as cv::resize stores it), centre-cropped to 112x112

@@ -73,6 +73,11 @@ int proj_impl(rgp_grcn* g, const float* c3d_input, const void* rows, hipStream_t
     nchw_to_rows_kernel<T><<<dim3(1024 / 64, g->F), 256, 0, s>>>(c3d_input, (T*)(g->ws + g->xt.off), 1024);
     RGP_HIP(hipGetLastError());
     A = g->ws + g->xt.off;
+  } else if (g->save) {
+    // the backward's projection wgrad reads xt in the reference's channel order c*2+d (gaze_rnn.py:494-497)
+    const long long total = (long long)g->F * 49 * 1024;
+    rows_to_xt_kernel<T><<<(int)std::min<long long>((total + 255) / 256, 8192), 256, 0, s>>>((const T*)rows, (T*)(g->ws + g->xt.off), total);
+    RGP_HIP(hipGetLastError());
   }
   IgemmParams p = make_params(d, A, g->ws, g->F);
   EpiParams e = make_epi(d, g->ws + g->E.off, g->ws);

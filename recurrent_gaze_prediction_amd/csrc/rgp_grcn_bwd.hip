@@ -18,6 +18,7 @@ using namespace rgp;
 
 struct GrcnBwd {
   ConvDesc b_d2, b_d1, b_c, b_zr, b_x;     // dgrad convolutions
+  ConvDesc b_px;                           // projection input gradient: d rows = dE x W^T
   // gather tables [ntaps][Mw] (element offsets, -1 = zero) + offsets in the workspace
   std::vector<int> t_E9, t_h9, t_dd1, t_dd2, t_y, t_d1, t_pad3S, t_pad2S, t_zero1, koff_m, koff_m2;
   size_t o_E9 = 0, o_h9 = 0, o_dd1 = 0, o_dd2 = 0, o_y = 0, o_d1 = 0, o_pad3S = 0, o_pad2S = 0,
@@ -181,7 +182,9 @@ int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   GrcnBwd* b = g->bwd;
   char* ws = g->ws;
   const int S = g->S, P = g->P;
-  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
+  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(b->b_px, w->proj_c3d_W, ws, 512, 0, s));            // d = 0: feature channels 0, 2, 4, ...
+  RGP_TRY(pack_filter<T>(b->b_px, w->proj_c3d_W + P, ws, 512, 512, s));      // d = 1: feature channels 1, 3, 5, ...
   RGP_TRY(pack_filter<T>(b->b_d2, w->up_weight2, ws, 64, 0, s));
   RGP_TRY(pack_filter<T>(b->b_d1, w->up_weight1, ws, S, 0, s));
   RGP_TRY(pack_filter<T>(b->b_c, w->gru_U, ws, S, 0, s));
@@ -248,8 +251,14 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   ok &= dgrad3x3(b->b_c, S, S, S, S);
   ok &= dgrad3x3(b->b_zr, 2 * S, S, S, S);
   ok &= dgrad3x3(b->b_x, 3 * S, P, P, P);
+  {  // d rows[m][d*512+c] = sum_p dE[m][p] W[c*2+d][p]   (gaze_grcn.py:225-254; rows order of rgp_c3d_forward)
+    ConvDesc& d = b->b_px;
+    d.Mw = 1; d.N = 1024; d.in_img_stride = P; d.out_img_stride = 1024; d.in_tab = {0}; d.out_tab = {0};
+    ok &= build_k_schedule(d, {0}, {0}, P, dtype);
+    d.s_tap = 0; d.s_n = 2LL * P; d.s_c = 1;
+  }
   if (!ok) return set_err(RGP_EINVAL, "rgp_grcn_create: backward K schedule failed");
-  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x}) d->reserve(a, dtype);
+  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) d->reserve(a, dtype);
 
   // ---- gather tables
   for (int t = 0; t < 9; ++t) for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x) {
@@ -312,7 +321,7 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
 
 int grcn_bwd_upload(rgp_grcn* g, hipStream_t s) {
   GrcnBwd* b = g->bwd;
-  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x}) RGP_TRY(upload_desc(*d, g->ws, s));
+  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) RGP_TRY(upload_desc(*d, g->ws, s));
   auto up = [&](const std::vector<int>& t, size_t off) -> int {
     RGP_HIP(hipMemcpyAsync(g->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
     return RGP_OK;
@@ -354,6 +363,17 @@ int rgp_grcn_backward(rgp_grcn_t* g, const float* logits, const float* probs, co
                               : backward_impl<float>(g, probs, logits, labels, grads, loss_type, s);
 }
 
+int rgp_grcn_backward_input(rgp_grcn_t* g, float* d_rows, rgp_stream_t stream) {
+  RGP_REQUIRE(g && d_rows, "rgp_grcn_backward_input: null argument");
+  if (!g->ws || !g->save || !g->bwd || !g->weights_set) return set_err(RGP_ESTATE, "rgp_grcn_backward_input: call after rgp_grcn_backward");
+  hipStream_t s = (hipStream_t)stream;
+  GrcnBwd* b = g->bwd;
+  IgemmParams p = make_params(b->b_px, g->ws + b->dE.off, g->ws, (int)b->M);
+  EpiParams e = make_epi(b->b_px, d_rows, g->ws);
+  return g->dtype == RGP_BF16 ? launch_igemm<bf16_t, 1, 1, EpiStore<float, false, false>>(p, e, s)
+                              : launch_igemm<float, 1, 1, EpiStore<float, false, false>>(p, e, s);
+}
+
 int rgp_adam_clip_step(float* params, const float* grads, float* m, float* v, long long n, float* workspace, int step,
                        float lr, float beta1, float beta2, float eps, float max_grad_norm, float* grad_norm_out,
                        rgp_stream_t stream) {
@@ -365,6 +385,27 @@ int rgp_adam_clip_step(float* params, const float* grads, float* m, float* v, lo
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   adam_clip_kernel<<<blocks, 256, 0, s>>>(params, grads, m, v, n, workspace, SQ_BLOCKS, max_grad_norm, lr_t, beta1, beta2,
                                           eps, grad_norm_out);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+int rgp_global_sqnorm(const float* grads, long long n, float* partials, rgp_stream_t stream) {
+  RGP_REQUIRE(grads && partials && n > 0, "rgp_global_sqnorm: bad arguments");
+  sqnorm_partial_kernel<<<SQ_BLOCKS, 256, 0, (hipStream_t)stream>>>(grads, n, partials);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+int rgp_adam_clip_step_ext(float* params, const float* grads, float* m, float* v, long long n, const float* partials,
+                           int n_partials, int step, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                           float* grad_norm_out, rgp_stream_t stream) {
+  RGP_REQUIRE(params && grads && m && v && partials && n > 0 && n_partials > 0 && step >= 0, "rgp_adam_clip_step_ext: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const double t = (double)step + 1.0;
+  const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+  adam_clip_kernel<<<blocks, 256, 0, s>>>(params, grads, m, v, n, partials, n_partials, max_grad_norm, lr_t, beta1, beta2, eps,
+                                          grad_norm_out);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }

@@ -41,6 +41,29 @@ def _as_dev_f32(x, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def adam_clip_step_multi(engines, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.clip_by_global_norm over the gradients of ALL engines (base.py:286-292) + TF Adam on each engine's flat
+    buffers, then repack.  engines: objects with flat_params / flat_grads (GrcnEngine, C3DEngine).
+    Returns a 1-element device tensor with the pre-clip global norm."""
+    lib, dev = engines[0].lib, engines[0].device
+    npart = _lib.RGP_SQNORM_PARTIALS
+    partials = torch.zeros(npart * len(engines), dtype=torch.float32, device=dev)
+    gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i, e in enumerate(engines):
+            _lib.check(lib.rgp_global_sqnorm(_ptr(e.flat_grads), e.flat_grads.numel(), _ptr(partials[i * npart:]),
+                                             _stream_ptr(dev)))
+        for e in engines:
+            if getattr(e, 'adam_m', None) is None:
+                e.adam_m, e.adam_v = torch.zeros_like(e.flat_params), torch.zeros_like(e.flat_params)
+            _lib.check(lib.rgp_adam_clip_step_ext(_ptr(e.flat_params), _ptr(e.flat_grads), _ptr(e.adam_m), _ptr(e.adam_v),
+                                                  e.flat_params.numel(), _ptr(partials), partials.numel(), int(step),
+                                                  float(lr), beta1, beta2, eps, float(max_grad_norm), _ptr(gnorm),
+                                                  _stream_ptr(dev)))
+            e.repack()
+    return gnorm
+
+
 class GrcnEngine(object):
     """gaze_grcn graph (models/gaze_grcn.py:173-376) at fixed (B, T, P, S, dtype)."""
 
@@ -111,6 +134,14 @@ class GrcnEngine(object):
             _lib.check(self.lib.rgp_grcn_backward(self._h, _ptr(logits), _ptr(probs), _ptr(labels), ctypes.byref(st),
                                                   {'xentropy': 0, 'l2': 1}[loss_type], _stream_ptr(self.device)))
         return self.grads
+
+    def backward_input(self, out=None):
+        """After backward(): d loss / d input as conv5b rows [B*T*49, 1024] fp32 (column d*512+c), the
+        gradient C3DEngine.backward(d_rows=...) consumes when the conv stack is fine-tuned."""
+        d = out if out is not None else torch.empty(self.B * self.T * 49, 1024, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_backward_input(self._h, _ptr(d), _stream_ptr(self.device)))
+        return d
 
     def adam_step(self, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8):
         """clip_by_global_norm + TF AdamOptimizer on the flat buffers (base.py:286-297), then repack.

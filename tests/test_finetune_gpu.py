@@ -1,0 +1,106 @@
+"""GPU: end-to-end fine-tune (video -> C3D -> gaze_grcn -> loss -> gradients into conv1a..conv5b)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref
+from recurrent_gaze_prediction_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def rms_rel(a, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.sqrt(((np.asarray(a, np.float64) - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-30))
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 3e-4), ('bf16', 4e-2)])
+def test_head_input_gradient_matches_autograd(gpu, dtype, tol):
+    """rgp_grcn_backward_input: d loss / d c3d_input, in the conv5b rows order."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    B, T = 2, 3
+    p = syn.grcn_params(51, T, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(52, B, T)
+    gt, _ = syn.gaze_maps(53, B, T)
+    gt = gt / gt.sum(axis=(2, 3), keepdims=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    loss = torch_ref.gaze_loss(torch_ref.grcn_forward(xt, {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}),
+                               torch.tensor(gt, dtype=torch.float64))
+    loss.backward()
+    ref = xt.grad.reshape(B * T, 512, 2, 49).permute(0, 3, 2, 1).reshape(B * T * 49, 1024).numpy()
+    eng = GrcnEngine(B, T, dtype=dtype, save_for_backward=True, device=gpu)
+    eng.set_weights(p)
+    logits, probs = eng.forward(torch.tensor(x, device=gpu))
+    eng.backward(logits, probs, torch.tensor(gt.astype(np.float32), device=gpu))
+    got = eng.backward_input().cpu().numpy()
+    assert np.abs(ref).max() > 0 and rel(got, ref) < tol, rel(got, ref)
+
+
+def _autograd_e2e(p3, ph, video, gt):
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    t3 = {k: torch.tensor(v, requires_grad=True) for k, v in p3.items()}
+    th = {k: torch.tensor(v, requires_grad=True) for k, v in ph.items()}
+    feat = torch_ref.c3d_forward(torch.tensor(video), t3)                      # [F,1024,7,7]
+    B, T = gt.shape[:2]
+    logits = torch_ref.grcn_forward(feat.reshape(B, T, 1024, 7, 7), th)
+    loss = torch_ref.gaze_loss(logits, torch.tensor(gt))
+    loss.backward()
+    torch.set_num_threads(old)
+    g = {'c3d/' + k: v.grad.numpy() for k, v in t3.items()}
+    g.update({'head/' + k: v.grad.numpy() for k, v in th.items()})
+    return float(loss.detach()), g
+
+
+def test_end_to_end_gradients_and_chunked_recompute(gpu):
+    """fp32 path: every gradient of the joint graph against CPU autograd (RMS level for the conv stack: the
+    pooling / ReLU routing of near-ties differs between any two fp32 implementations, see
+    test_c3d_backward_gpu); chunked backward with recomputation gives the same gradients."""
+    from recurrent_gaze_prediction_amd.finetune import EndToEndGaze
+    B, T = 1, 2
+    p3, ph = syn.c3d_params(61), syn.grcn_params(62, T, gru_std=0.05, random_bn=True)
+    rs = np.random.RandomState(63)
+    video = (rs.rand(B * T, 16, 112, 112, 3).astype(np.float32) - 0.5) * 2
+    gt, _ = syn.gaze_maps(64, B, T)
+    gt = (gt / gt.sum(axis=(2, 3), keepdims=True)).astype(np.float32)
+    loss_ref, g_ref = _autograd_e2e(p3, ph, video, gt)
+    m = EndToEndGaze(B, T, dtype='f32', device=gpu, c3d_params=p3, grcn_params=ph)
+    v, lab = torch.tensor(video, device=gpu), torch.tensor(gt, device=gpu)
+    logits, probs = m.forward(v)
+    loss = float(m.backward(v, logits, probs, lab))
+    assert abs(loss - loss_ref) < 1e-4 * abs(loss_ref)
+    got = {k: t.cpu().numpy().copy() for k, t in m.gradients().items()}
+    errs = {k: rms_rel(got[k], g_ref[k]) for k in g_ref if np.abs(g_ref[k]).max() > 1e-12}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert max(e for k, e in errs.items() if k.startswith('head/') and k != 'head/out_b') < 2e-3, worst
+    assert max(e for k, e in errs.items() if k.startswith('c3d/')) < 5e-2, worst
+    m2 = EndToEndGaze(B, T, dtype='f32', device=gpu, max_windows=1, c3d_params=p3, grcn_params=ph)
+    l2, p2 = m2.forward(v)
+    m2.backward(v, l2, p2, lab)
+    for k, t in m2.gradients().items():
+        assert rel(t.cpu().numpy(), got[k]) < 1e-4 or np.abs(got[k]).max() < 1e-12, k
+
+
+def test_train_steps_reduce_the_loss(gpu):
+    """bf16 operands: a few joint Adam steps on one fixed batch lower the loss; both parameter sets move."""
+    from recurrent_gaze_prediction_amd.finetune import EndToEndGaze
+    B, T = 2, 2
+    m = EndToEndGaze(B, T, dtype='bf16', device=gpu, seed=7)
+    rs = np.random.RandomState(71)
+    v = torch.tensor((rs.rand(B * T, 16, 112, 112, 3).astype(np.float32) - 0.5) * 2, device=gpu)
+    gt, _ = syn.gaze_maps(72, B, T)
+    lab = torch.tensor((gt / gt.sum(axis=(2, 3), keepdims=True)).astype(np.float32), device=gpu)
+    w0 = m.c3d.flat_params.clone()
+    h0 = m.head.flat_params.clone()
+    losses = []
+    for _ in range(6):
+        loss, gnorm = m.train_step(v, lab, lr=1e-3)
+        losses.append(float(loss))
+        assert np.isfinite(losses[-1]) and float(gnorm) > 0
+    assert losses[-1] < losses[0], losses
+    assert float((m.c3d.flat_params - w0).abs().max()) > 0 and float((m.head.flat_params - h0).abs().max()) > 0
