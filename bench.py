@@ -51,8 +51,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['e2e', 'head', 'train'], default='e2e',
-                    help="train = head training step on precomputed features (BASELINE config 4: fwd + bwd + "
+    ap.add_argument('--workload', choices=['e2e', 'head', 'train', 'finetune'], default='e2e',
+                    help="finetune = end-to-end training step incl. the conv stack's backward (BASELINE config 5 style); "
+                         "train = head training step on precomputed features (BASELINE config 4: fwd + bwd + "
                          "gradient all-reduce + clipped Adam; pass --batch 8 --n-steps 35 for its shape)")
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--n-steps', type=int, default=16, help='RNN timesteps T per clip')
@@ -112,13 +113,29 @@ def main():
     dist = rdist.init(backend='nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
     B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
 
-    head = GrcnEngine(B, T, dtype=args.dtype, save_for_backward=args.workload == 'train', device=dev)
-    head.set_weights(syn.grcn_params(1, T))
-    logits = torch.empty(B, T, 49, 49, device=dev)
-    probs = torch.empty_like(logits)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    if args.workload == 'e2e':
+    ft = None
+    if args.workload == 'finetune':
+        from recurrent_gaze_prediction_amd.finetune import EndToEndGaze
+        ft = EndToEndGaze(B, T, dtype=args.dtype, device=dev, max_windows=min(args.c3d_chunk, F), seed=1)
+        ft.attach_process_group(dist)
+        head, c3d = ft.head, ft.c3d
+    else:
+        head = GrcnEngine(B, T, dtype=args.dtype, save_for_backward=args.workload == 'train', device=dev)
+        head.set_weights(syn.grcn_params(1, T))
+    logits = torch.empty(B, T, 49, 49, device=dev)
+    probs = torch.empty_like(logits)
+    if ft is not None:
+        video = torch.rand(F, 16, 112, 112, 3, device=dev, generator=g) - 0.5
+        gt = torch.rand(B, T, 49, 49, device=dev, generator=g) + 1e-3
+        gt = (gt / gt.sum((-1, -2), keepdim=True)).contiguous()
+        last = {}
+
+        def step():
+            k = ft.global_step
+            last['loss'], last['gnorm'] = ft.train_step(video, gt, 1e-4 * 0.8 ** (k // 500), max_grad_norm=10.0)
+    elif args.workload == 'e2e':
         c3d = C3DEngine(min(args.c3d_chunk, F), dtype=args.dtype, device=dev)
         c3d.set_weights(syn.c3d_params(2))
         video = torch.rand(F, 16, 112, 112, 3, device=dev, generator=g) - 0.5   # U(0,1)-0.5, resident in HBM
@@ -163,7 +180,10 @@ def main():
     elapsed = rdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
     hprof = head.profile_read()
     cprof = c3d.profile_read() if c3d is not None else {}
-    assert torch.isfinite(probs).all(), 'non-finite saliency maps'
+    if ft is not None:
+        assert bool(torch.isfinite(last['loss'])) and bool(torch.isfinite(last['gnorm'])), 'non-finite training step'
+    else:
+        assert torch.isfinite(probs).all(), 'non-finite saliency maps'
 
     if rank == 0:
         frames_total = world * F * args.steps
@@ -198,13 +218,21 @@ def main():
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
                     'algorithmic_gflop_per_launch': round(flops / max(calls, 1) / 1e9, 3)}
         flops_frame = HEAD_FLOPS_FRAME + (C3D_FLOPS_FRAME if c3d is not None else 0.0)
+        if ft is not None:
+            from recurrent_gaze_prediction_amd.finetune import flops_per_frame_train
+            flops_frame = flops_per_frame_train()
         out = {
             'metric': 'frames/sec (49x49 saliency maps), gaze_grcn 16-frame clips',
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ('gaze_grcn end-to-end: synthetic 16x112x112x3 windows -> C3D conv1a-5b -> '
+            'config': {'workload': ('gaze_grcn END-TO-END TRAINING step: synthetic 16x112x112x3 windows -> C3D conv1a-5b (arg-max '
+                                    'recorded) -> gaze_grcn head -> xentropy loss -> head backward -> conv-stack backward '
+                                    '(dgrad + wgrad of all 8 layers) -> gradient all-reduce -> global-norm clip + TF-Adam on '
+                                    'all 30.7 M variables; roofline = dominant FORWARD kernel of the step'
+                                    if ft is not None else
+                                    'gaze_grcn end-to-end: synthetic 16x112x112x3 windows -> C3D conv1a-5b -> '
                                     '1024->512 proj -> ConvGRU(512->128, 7x7) -> deconv head -> 49x49 softmax maps'
                                     if c3d is not None else
                                     'gaze_grcn head on precomputed C3D conv5b features [B,T,1024,7,7]'
@@ -214,13 +242,15 @@ def main():
                        'clips_per_gpu': B, 'n_lstm_steps': T, 'frames_per_step_per_gpu': F,
                        'parallelism': ('dp%d (clip-sharded, one flat RCCL all-reduce of the 12 MB gradient per step)' % world
                                        if args.workload == 'train' else
+                                       'dp%d (clip-sharded, RCCL all-reduce of the 12 MB head + 110.6 MB conv gradient buckets per step)' % world
+                                       if ft is not None else
                                        'dp%d (clip-sharded replicas, no collective)' % world),
                        'weights': 'random init (reference initialisers), GRU filters std 0.05'},
             'algorithmic_tflops': round(value * flops_frame / 1e12, 2),
             'stage_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in list(cprof.items()) + list(hprof.items())},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload != 'train':
+        if world == 1 and not args.no_cpu_baseline and args.workload in ('e2e', 'head'):
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
         print(json.dumps(out))

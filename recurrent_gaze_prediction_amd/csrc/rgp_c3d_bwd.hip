@@ -38,6 +38,20 @@ __global__ __launch_bounds__(256) void rows_grad_kernel(const float* __restrict_
   }
 }
 
+// Per-block reduction of the threads' 8-channel partial sums (thread = (row lane rl, channel group cg)),
+// then ONE atomic per channel and block: thousands of threads adding to the same C addresses serialise.
+__device__ __forceinline__ void block_colsum(const float* bsum, int cg, int rl, int RL, int C, float* __restrict__ db) {
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rl * C + cg * 8 + k] = bsum[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < RL; ++r) a += red[r * C + c];
+    if (a != 0.f) atomicAdd(db + c, a);
+  }
+}
+
 // Pooled layer: scatter dYp [n][PR][C] into dYpre through the recorded arg-max, gate by the pooled
 // forward output y > 0, and accumulate the bias gradient.  Thread = (row lane, 8-channel group).
 template <typename T>
@@ -72,9 +86,7 @@ __global__ __launch_bounds__(256) void unpool_kernel(const T* __restrict__ dyp, 
       store8<T>(base + q_off[q], v, 8);
     }
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (bsum[k] != 0.f) atomicAdd(db + cg * 8 + k, bsum[k]);
+  block_colsum(bsum, cg, rl, RL, C, db);
 }
 
 // Bias gradient of an un-pooled layer: column sums over the interior rows of dYpre.
@@ -91,9 +103,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ buf, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) bsum[k] += Elem<T>::from(p[k]);
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (bsum[k] != 0.f) atomicAdd(db + cg * 8 + k, bsum[k]);
+  block_colsum(bsum, cg, rl, RL, C, db);
 }
 
 // conv1a: packed K order ((kz,ky) tap, kx 0..3, c 0..3) -> DHWIO [3,3,3,3,64], accumulated
@@ -153,8 +163,14 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       WgradParams p;
       p.X = ws + c->act_off[i];
       p.dY = ws + b.dypre_off;
-      p.x_tab = (const int*)(ws + b.x_tab_off);
-      p.y_tab = (const int*)(ws + b.y_tab_off);
+      {
+        const int Hp = l.H + 2, Wp = l.H + 2, Cx = i == 0 ? 4 : l.cin, Wpx = i == 0 ? l.H + 4 : l.H + 2;
+        p.D = l.D; p.H = l.H; p.W = l.H;
+        p.inv_D = 1.0f / l.D; p.inv_H = 1.0f / l.H; p.inv_W = 1.0f / l.H;
+        p.x_sx = Cx; p.x_sy = Wpx * Cx; p.x_sz = Hp * Wpx * Cx;
+        p.y_sx = l.cout; p.y_sy = Wp * l.cout; p.y_sz = Hp * Wp * l.cout;
+        p.y_org = p.y_sz + p.y_sy + p.y_sx;
+      }
       p.koff = (const int*)(ws + c->L[i].koff_off);
       p.x_img_stride = c->act_stride[i];
       p.y_img_stride = b.dypre_stride;

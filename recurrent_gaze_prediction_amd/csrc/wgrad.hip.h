@@ -27,8 +27,13 @@ struct WgradParams {
   const void* dY;          // gradient w.r.t. the conv output before pooling, halo-padded (operand dtype);
                            // its first 128*sizeof(T) bytes must be zero (they are: halo)
   float* dW;               // [nk*BKE][ldw] fp32, accumulated with atomics
-  const int* x_tab;        // [Mw] element offset of row m's window origin inside one X image
-  const int* y_tab;        // [Mw] element offset of row m inside one dY image
+  // Row m of an image is the output position (z, y, x), m = (z*H + y)*W + x.  Its window origin in X is
+  // z*x_sz + y*x_sy + x*x_sx elements, its position in dY is y_org + z*y_sz + y*y_sy + x*y_sx.  The offsets
+  // are computed, not looked up: a per-lane table load inside the loop would sit in the same in-order
+  // vmcnt queue as the LDS-DMA and force the ring to drain.
+  int D, H, W;
+  int x_sz, x_sy, x_sx, y_sz, y_sy, y_sx, y_org;
+  float inv_W, inv_H, inv_D;
   const int* koff;         // [nk*G] element offset of each K (sub-)chunk
   long long x_img_stride, y_img_stride;
   long long M;             // rows = images * Mw
@@ -37,6 +42,8 @@ struct WgradParams {
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct WgradSmem {
   static constexpr int XB = 4 * 32 * 128;                    // 4 chunks x 32 rows x 128 B
@@ -96,27 +103,35 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     const int phys = ESZ == 2 ? (tid & 15) : (tid & 31);
     yc[u] = phys ^ wg_swz_y<T>(yr[u]);
   }
-  // running (image, row-in-image) of each owned row
-  int x_img, x_ml, y_img[NYL], y_ml[NYL];
-  {
-    const long long m = m_begin + xr;
-    x_img = (int)(m / p.Mw);
-    x_ml = (int)(m - (long long)x_img * p.Mw);
+  // running (image, z, y, x) of each owned row; a step advances every row by 32
+  struct RowPos { int img, z, y, x; };
+  auto locate = [&](long long m) {
+    RowPos r;
+    r.img = (int)(m / p.Mw);
+    int ml = (int)(m - (long long)r.img * p.Mw);
+    r.x = ml % p.W; ml /= p.W;
+    r.y = ml % p.H;
+    r.z = ml / p.H;
+    return r;
+  };
+  auto advance = [&](RowPos& r) {
+    r.x += 32;
+    int t = (int)(((float)r.x + 0.5f) * p.inv_W); r.x -= t * p.W; r.y += t;
+    t = (int)(((float)r.y + 0.5f) * p.inv_H); r.y -= t * p.H; r.z += t;
+    t = (int)(((float)r.z + 0.5f) * p.inv_D); r.z -= t * p.D; r.img += t;
+  };
+  RowPos xpos = locate(m_begin + xr), ypos[NYL];
 #pragma unroll
-    for (int u = 0; u < NYL; ++u) {
-      const long long my = m_begin + yr[u];
-      y_img[u] = (int)(my / p.Mw);
-      y_ml[u] = (int)(my - (long long)y_img[u] * p.Mw);
-    }
-  }
-  int x_step = 0, y_step = 0;     // steps already issued
+  for (int u = 0; u < NYL; ++u) ypos[u] = locate(m_begin + yr[u]);
+  int n_issued = 0;
 
   auto issue = [&](int buf) {
     char* xb = smem + buf * S::STAGE;
     char* yb = xb + S::XB;
+    const long long m_step = m_begin + (long long)n_issued * 32;
     {
-      const bool ok = m_begin + (long long)x_step * 32 + xr < m_end;
-      const long long base = ok ? ((long long)x_img * p.x_img_stride + p.x_tab[x_ml]) * ESZ : 0;
+      const bool ok = m_step + xr < m_end;
+      const long long base = ((long long)xpos.img * p.x_img_stride + xpos.z * p.x_sz + xpos.y * p.x_sy + xpos.x * p.x_sx) * ESZ;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const char* src = ok ? xsrc_k[u] + base : (const char*)p.X;
@@ -124,23 +139,21 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
                                          (__attribute__((address_space(3))) void*)(xb + ((wave >> 2) + 2 * u) * 4096 + (wave & 3) * 1024),
                                          16, 0, 0);
       }
-      x_ml += 32;
-      while (x_ml >= p.Mw) { x_ml -= p.Mw; ++x_img; }
-      ++x_step;
+      advance(xpos);
     }
 #pragma unroll
     for (int u = 0; u < NYL; ++u) {
-      const bool ok = m_begin + (long long)y_step * 32 + yr[u] < m_end;
+      const bool ok = m_step + yr[u] < m_end;
+      const RowPos& r = ypos[u];
       const char* src = (const char*)p.dY;
-      if (ok) src += (((long long)y_img[u] * p.y_img_stride + p.y_tab[y_ml[u]]) + n0) * ESZ + yc[u] * 16;
+      if (ok) src += ((long long)r.img * p.y_img_stride + p.y_org + r.z * p.y_sz + r.y * p.y_sy + r.x * p.y_sx + n0) * ESZ + yc[u] * 16;
       else src += (yc[u] & 7) * 16;                                        // zeros (halo)
       const int ldsoff = ESZ == 2 ? wave * 1024 : (16 * u + 2 * wave) * 512;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(yb + ldsoff), 16, 0, 0);
-      y_ml[u] += 32;
-      while (y_ml[u] >= p.Mw) { y_ml[u] -= p.Mw; ++y_img[u]; }
+      advance(ypos[u]);
     }
-    ++y_step;
+    ++n_issued;
   };
 
   f32x4 acc[CI][4];
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fcol = lane & 15, g = lane >> 4;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto compute = [&](int buf) {
     const char* xb = smem + buf * S::STAGE + wk * 4096;
     const char* yb = smem + buf * S::STAGE + S::XB;
@@ -157,22 +171,39 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
       const int q = fcol >> 2, pp = fcol & 3;
       const int row = 8 * g + q;                                 // rows row and row+4 share the swizzle
       const int sx = (wg_swz_x<T>(row) >> 1), sy = (wg_swz_y<T>(row) >> 1);
+      // The transposing reads are written as inline asm: issued through the builtin, the compiler orders
+      // every LDS read after ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which drains the two tiles in
+      // flight and serialises the ring.  The asm carries its own lgkmcnt wait; A's registers are consumed
+      // only by MFMAs that also need B's, so one wait at the end of the second block covers both.
+      static_assert(CI == 4, "bf16 chunk = 4 x 16 filter rows");
+      const unsigned xa = lds_base + (unsigned)(xb - smem) + row * 128 + pp * 8;
+      const unsigned ya = lds_base + (unsigned)(yb - smem) + row * 256 + pp * 8;
+      i32x2 al[4], ah[4], bl[4], bh[4];
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:512\n\t"
+          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:512\n\t"
+          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:512"
+          : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&v"(al[3]), "=&v"(ah[3])
+          : "v"(xa + ((0 ^ sx) * 32)), "v"(xa + ((1 ^ sx) * 32)), "v"(xa + ((2 ^ sx) * 32)), "v"(xa + ((3 ^ sx) * 32))
+          : "memory");
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
+          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1024\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(bl[0]), "=&v"(bh[0]), "=&v"(bl[1]), "=&v"(bh[1]), "=&v"(bl[2]), "=&v"(bh[2]), "=&v"(bl[3]), "=&v"(bh[3])
+          : "v"(ya + (((wn * 4 + 0) ^ sy) * 32)), "v"(ya + (((wn * 4 + 1) ^ sy) * 32)), "v"(ya + (((wn * 4 + 2) ^ sy) * 32)),
+            "v"(ya + (((wn * 4 + 3) ^ sy) * 32))
+          : "memory");
       f32x4 a[CI], b[4];
 #pragma unroll
-      for (int i = 0; i < CI; ++i) {
-        const char* ad = xb + row * 128 + ((i ^ sx) * 32) + pp * 8;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ad);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 512));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        a[i] = __builtin_bit_cast(f32x4, v);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const char* bd = yb + row * 256 + (((wn * 4 + j) ^ sy) * 32) + pp * 8;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)bd);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bd + 1024));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        b[j] = __builtin_bit_cast(f32x4, v);
+      for (int i = 0; i < 4; ++i) {
+        const i32x4 va = {al[i][0], al[i][1], ah[i][0], ah[i][1]};
+        const i32x4 vb = {bl[i][0], bl[i][1], bh[i][0], bh[i][1]};
+        a[i] = __builtin_bit_cast(f32x4, va);
+        b[i] = __builtin_bit_cast(f32x4, vb);
       }
 #pragma unroll
       for (int i = 0; i < CI; ++i)
