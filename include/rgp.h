@@ -115,6 +115,12 @@ int rgp_softmax_xent_fwd(const float* logits, const float* labels, float* probs,
 int rgp_grcn_backward(rgp_grcn_t* plan, const float* logits, const float* probs, const float* labels,
                       const rgp_grcn_weights* grads, int loss_type, rgp_stream_t stream);
 
+/* Backward of the projection + ConvGRU only, for a network that stacks its own layers on the states
+ * (the cascade, gaze_grcn_cascade.py:289-336): d_states [B*T*49, S] fp32 is the gradient w.r.t. the
+ * batch-normalised states in frame order b*T+t; the head fields of grads receive zeros. */
+int rgp_grcn_backward_from_states(rgp_grcn_t* plan, const float* d_states, const rgp_grcn_weights* grads,
+                                  rgp_stream_t stream);
+
 /* After rgp_grcn_backward: the gradient w.r.t. the network input, d_rows [B*T*49, 1024] fp32 in the column
  * order of the conv5b rows (d*512 + c) -- what rgp_c3d_backward takes when the conv stack is fine-tuned
  * end to end (BASELINE config 5). */
@@ -216,6 +222,15 @@ int rgp_cascade_set_weights(rgp_cascade_t* plan, const rgp_cascade_weights* w, r
  * (predicted_gazemaps of gaze_grcn_cascade.py:423, trained with loss_type l2). */
 int rgp_cascade_forward(rgp_cascade_t* plan, const float* frame_images, const float* c3d_input, float* gazemaps,
                         rgp_stream_t stream);
+/* Training (BASELINE config 5).  rgp_cascade_create_ex(save_for_backward = 1) keeps the gates, states and
+ * maxout masks of the forward.  rgp_cascade_backward differentiates the l2 loss of gaze_grcn_cascade.py:428-441
+ * (sum_t 0.5 ||maps - gt||^2 / (B*T)) w.r.t. every non-ShallowNet variable (the ShallowNet has learning rate
+ * 0, base.py:264-265): grads is shaped like the weights, every listed array is fully overwritten, the
+ * shallownet sub-struct is ignored.  d_rows (optional, [B*T*49, 1024] fp32) receives the gradient w.r.t. the
+ * C3D conv5b rows for rgp_c3d_backward (end-to-end fine-tune). */
+int rgp_cascade_create_ex(rgp_cascade_t** plan, int batch, int n_steps, int image_hw, int dtype, int save_for_backward);
+int rgp_cascade_backward(rgp_cascade_t* plan, const float* gazemaps, const float* gt_gazemap, const rgp_cascade_weights* grads,
+                         float* d_rows, rgp_stream_t stream);
 /* Intermediates of the last forward as dense fp32 (net[...] keys of gaze_grcn_cascade.py):
  * "frm_sal" [B*T,49,49], "rcn_outputs" [B,T,7,7,256], "rcn_upsampled_outputs" [B*T,49,49,64],
  * "gaze_rcn_outputs" [B*T,49,49,3] (top-cell states). */

@@ -73,6 +73,7 @@ SIGNATURES = {
     'rgp_grcn_read_buffer': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
     'rgp_grcn_buffer_elems': (c_size_t, [c_void_p, c_char_p]),
     'rgp_grcn_backward_input': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'rgp_grcn_backward_from_states': (c_int, [c_void_p, c_void_p, ctypes.POINTER(GrcnWeights), c_void_p]),
     'rgp_softmax_xent_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'rgp_fcgru_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
     'rgp_fcgru_destroy': (c_int, [c_void_p]),
@@ -93,6 +94,8 @@ SIGNATURES = {
     'rgp_cascade_set_weights': (c_int, [c_void_p, ctypes.POINTER(CascadeWeights), c_void_p]),
     'rgp_cascade_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rgp_cascade_read_buffer': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
+    'rgp_cascade_create_ex': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    'rgp_cascade_backward': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(CascadeWeights), c_void_p, c_void_p]),
     'rgp_c3d_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int]),
     'rgp_c3d_destroy': (c_int, [c_void_p]),
     'rgp_c3d_workspace_bytes': (c_size_t, [c_void_p]),

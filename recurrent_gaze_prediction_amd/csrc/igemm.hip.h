@@ -171,6 +171,8 @@ template <typename TO> struct EpiReluMaxout {
       if (2 * i + 1 < nvalid) {
         const float a = fmaxf(v[2 * i] + e.bias[n0 + 2 * i], 0.f), b = fmaxf(v[2 * i + 1] + e.bias[n0 + 2 * i + 1], 0.f);
         dst[i] = Elem<TO>::to(fmaxf(a, b));
+        // training: which half carries the gradient (tf.maximum sends ties to the first operand), 0 = ReLU-gated
+        if (e.argmax) e.argmax[(long long)img * (N >> 1) + (n0 >> 1) + i] = fmaxf(a, b) > 0.f ? (a >= b ? 1 : 2) : 0;
       }
     }
   }

@@ -13,7 +13,7 @@
 #include <algorithm>
 
 #include "rgp_c3d_plan.h"
-#include "wgrad.hip.h"
+#include "wgrad_launch.h"
 
 using namespace rgp;
 
@@ -115,27 +115,6 @@ __global__ void conv1a_unpack_grad_kernel(const float* __restrict__ dw1, float* 
   grad[i] += dw1[(long long)(t2 * 16 + kx * 4 + c) * 64 + n];
 }
 
-template <typename T, int G>
-int launch_wgrad(const WgradParams& p, hipStream_t s) {
-  auto kern = wgrad_kernel<T, G>;
-  constexpr int smem = WgradSmem<T>::BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
-  const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + 127) / 128;
-  const long long total_steps = (p.M + 31) / 32;
-  long long splits = std::max<long long>(1, 1024 / (n_kt * n_nt));
-  splits = std::min(splits, total_steps);
-  WgradParams q = p;
-  q.steps_per_split = (int)((total_steps + splits - 1) / splits);
-  splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
-  kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
-  RGP_HIP(hipGetLastError());
-  return RGP_OK;
-}
-
 template <typename T>
 int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, float* grads, hipStream_t s) {
   char* ws = c->ws;
@@ -179,6 +158,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       p.N = l.cout;
       p.nk = c->L[i].nk;
       p.ldw = l.cout;
+      p.k_valid = c->L[i].nk * Elem<T>::BKE;
       p.steps_per_split = 0;
       if (i == 0) {
         p.dW = (float*)(ws + c->dw1_off);

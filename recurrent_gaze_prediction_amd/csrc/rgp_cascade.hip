@@ -17,31 +17,9 @@
 #include <algorithm>
 #include <string>
 
-#include "rgp_grcn_plan.h"
+#include "rgp_cascade_plan.h"
 
 using namespace rgp;
-
-namespace {
-constexpr int kCt = 128;   // top-cell input channels: 64 upsampled + 1 saliency, zero-padded
-constexpr int kSt = 16;    // top-cell state channels: 3 units, zero-padded
-constexpr int kHp = 53;    // 49 + 2*2 halo for the 5x5 SAME convs
-}  // namespace
-
-struct rgp_cascade {
-  int B = 0, T = 0, F = 0, dtype = RGP_BF16, image_hw = 98;
-  rgp_grcn* bottom = nullptr;
-  rgp_shallownet_t* shallow = nullptr;
-  std::vector<ConvDesc> up;             // 49 phases of the stride-7 transposed conv
-  ConvDesc xtop, zr, c, fc1, fc2;
-  std::vector<int> tab_pad53_t, tab_pad53_x;   // interior of a 53x53xkSt / 53x53xkCt image
-  size_t o_pad53_t = 0, o_pad53_x = 0;
-  size_t off_bottom = 0, off_shallow = 0, sal = 0, xtopbuf = 0, xpre = 0, hall = 0, u = 0, hp = 0, rh = 0, hrows = 0,
-         fcin = 0, mo1 = 0, b1i = 0, b2i = 0, ones = 0, zeros = 0, bn_id = 0;
-  int Kfc = 0, K2 = 0;
-  size_t ws_bytes = 0;
-  char* ws = nullptr;
-  bool weights_set = false;
-};
 
 namespace {
 
@@ -209,25 +187,37 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
   }
   const size_t st = (size_t)B * 2401 * kSt;
-  RGP_HIP(hipMemsetAsync(ws + g->hp, 0, (size_t)B * kHp * kHp * kSt * sizeof(T), s));
-  RGP_HIP(hipMemsetAsync(ws + g->hall, 0, st * 4, s));
-  float* hall = (float*)(ws + g->hall);
+  const long long img16 = (long long)kHp * kHp * kSt;
+  // inference: two state snapshots and one operand image per role; training: every step's states, gates and
+  // operand images are kept (hp_all slot (b, t) = h_{t-1} of step t, slot (b, 0) is never written = h_0 = 0)
+  const bool save = g->save;
+  if (!save) RGP_HIP(hipMemsetAsync(ws + g->hp, 0, (size_t)B * img16 * sizeof(T), s));
+  float* hall = (float*)(ws + (save ? g->hall_t : g->hall));
+  RGP_HIP(hipMemsetAsync(hall, 0, st * 4, s));
   for (int t = 0; t < T_; ++t) {
-    EpiParams e = make_epi(g->zr, ws + g->rh, ws);
+    char* hp_in = save ? ws + g->hp_all + (size_t)t * img16 * sizeof(T) : ws + g->hp;
+    char* hp_out = save ? ws + g->hp_all + (size_t)(t + 1) * img16 * sizeof(T) : ws + g->hp;
+    char* rh_buf = save ? ws + g->rhp_all + (size_t)t * img16 * sizeof(T) : ws + g->rh;
+    const long long hp_stride = save ? (long long)(T_ + 1) * img16 : img16, rh_stride = save ? (long long)T_ * img16 : img16;
+    EpiParams e = make_epi(g->zr, rh_buf, ws);
     e.out_tab = (const int*)(ws + g->o_pad53_t);
-    e.out_img_stride = (long long)kHp * kHp * kSt;
+    e.out_img_stride = rh_stride;
     e.xpre = (const float*)(ws + g->xpre) + (size_t)t * 2401 * 3 * kSt;
     e.xpre_img_stride = (long long)T_ * 2401 * 3 * kSt;
     e.xpre_ld = 3 * kSt;
     e.xpre_col = 0;
     e.S = kSt;
     e.state_rows = 2401;
-    e.h_prev = hall + (size_t)(t & 1) * st;
-    e.h_next = hall + (size_t)((t + 1) & 1) * st;
-    e.u_gate = (float*)(ws + g->u);
-    IgemmParams p = make_params(g->zr, ws + g->hp, ws, B);
+    e.h_prev = hall + (size_t)(save ? t : (t & 1)) * st;
+    e.h_next = hall + (size_t)(save ? t + 1 : ((t + 1) & 1)) * st;
+    e.u_gate = save ? (float*)(ws + g->uall) + (size_t)t * st : (float*)(ws + g->u);
+    e.r_save = save ? (float*)(ws + g->rall) + (size_t)t * st : nullptr;
+    e.c_save = save ? (float*)(ws + g->call) + (size_t)t * st : nullptr;
+    IgemmParams p = make_params(g->zr, hp_in, ws, B);
+    p.in_img_stride = hp_stride;
     RGP_TRY((launch_igemm<T, G16, 1, EpiGruZR<T>>(p, e, s)));
-    e.out = ws + g->hp;
+    e.out = hp_out;
+    e.out_img_stride = hp_stride;
     e.xpre_col = 2 * kSt;
     e.out2 = ws + g->hrows;
     e.out2_tab = (const int*)(ws + g->c.out_tab_off);      // dense [2401][kSt] rows
@@ -237,7 +227,8 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
     e.bn_gamma = (const float*)(ws + g->ones);
     e.bn_beta = (const float*)(ws + g->zeros);
     e.bn_inv_std = 1.0f;
-    IgemmParams pc = make_params(g->c, ws + g->rh, ws, B);
+    IgemmParams pc = make_params(g->c, rh_buf, ws, B);
+    pc.in_img_stride = rh_stride;
     RGP_TRY((launch_igemm<T, G16, 1, EpiGruC<T>>(pc, e, s)));
   }
   // (5) flatten + two maxout FCs
@@ -251,12 +242,14 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
     IgemmParams p = make_params(g->fc1, ws + g->fcin, ws, F);
     EpiParams e = make_epi(g->fc1, ws + g->mo1, ws);
     e.bias = (const float*)(ws + g->b1i);
+    if (save) e.argmax = (unsigned char*)(ws + g->mask1);
     RGP_TRY((launch_igemm<T, 1, 1, EpiReluMaxout<T>>(p, e, s)));
   }
   {
     IgemmParams p = make_params(g->fc2, ws + g->mo1, ws, F);
     EpiParams e = make_epi(g->fc2, maps, ws);
     e.bias = (const float*)(ws + g->b2i);
+    if (save) e.argmax = (unsigned char*)(ws + g->mask2);
     RGP_TRY((launch_igemm<T, 1, 1, EpiReluMaxout<float>>(p, e, s)));
   }
   return RGP_OK;
@@ -267,11 +260,16 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
 extern "C" {
 
 int rgp_cascade_create(rgp_cascade_t** plan, int batch, int n_steps, int image_hw, int dtype) {
+  return rgp_cascade_create_ex(plan, batch, n_steps, image_hw, dtype, 0);
+}
+
+int rgp_cascade_create_ex(rgp_cascade_t** plan, int batch, int n_steps, int image_hw, int dtype, int save_for_backward) {
   RGP_REQUIRE(plan && batch > 0 && n_steps > 0, "rgp_cascade_create: bad arguments");
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_cascade_create: dtype %d", dtype);
   rgp_cascade* g = new rgp_cascade();
   g->B = batch; g->T = n_steps; g->F = batch * n_steps; g->dtype = dtype; g->image_hw = image_hw;
-  int rc = rgp_grcn_create(&g->bottom, batch, n_steps, 512, 256, dtype, 0);
+  g->save = save_for_backward != 0;
+  int rc = rgp_grcn_create(&g->bottom, batch, n_steps, 512, 256, dtype, g->save ? 1 : 0);
   if (rc == RGP_OK) rc = rgp_shallownet_create(&g->shallow, g->F, image_hw, dtype);
   if (rc != RGP_OK) { rgp_cascade_destroy(g); return rc; }
   const int es = esize(dtype), F = g->F;
@@ -315,6 +313,10 @@ int rgp_cascade_create(rgp_cascade_t** plan, int batch, int n_steps, int image_h
   g->ones = a.take(kSt * 4);
   g->zeros = a.take(kSt * 4);
   g->bn_id = a.take(((size_t)2 * n_steps * 256 + 25 * 64 * 256) * 4);
+  if (g->save) {
+    rc = cascade_bwd_plan(g, a);
+    if (rc != RGP_OK) { rgp_cascade_destroy(g); return rc; }
+  }
   g->ws_bytes = a.off;
   *plan = g;
   return RGP_OK;
@@ -347,6 +349,7 @@ int rgp_cascade_bind_workspace(rgp_cascade_t* g, void* workspace, size_t bytes, 
   RGP_HIP(hipMemcpyAsync(g->ws + g->o_pad53_x, g->tab_pad53_x.data(), g->tab_pad53_x.size() * 4, hipMemcpyHostToDevice, s));
   fill2_kernel<<<1, 64, 0, s>>>((float*)(g->ws + g->ones), 1.0f, kSt);
   RGP_HIP(hipGetLastError());
+  if (g->save) RGP_TRY(cascade_bwd_upload(g, s));
   return RGP_OK;
 }
 
@@ -357,7 +360,9 @@ int rgp_cascade_set_weights(rgp_cascade_t* g, const rgp_cascade_weights* w, rgp_
   for (size_t i = 0; i < sizeof(rgp_cascade_weights) / sizeof(float*); ++i)
     RGP_REQUIRE(ptrs[i], "rgp_cascade_set_weights: weight pointer %zu is null", i);
   hipStream_t s = (hipStream_t)stream;
-  return g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s) : set_weights_impl<float>(g, w, s);
+  RGP_TRY(g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s) : set_weights_impl<float>(g, w, s));
+  if (g->save) RGP_TRY(cascade_bwd_pack(g, w, s));
+  return RGP_OK;
 }
 
 int rgp_cascade_forward(rgp_cascade_t* g, const float* frame_images, const float* c3d_input, float* gazemaps,

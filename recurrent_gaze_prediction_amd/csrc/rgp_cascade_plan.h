@@ -1,0 +1,53 @@
+// Plan object of the two-level cascade, shared by rgp_cascade.hip (forward) and rgp_cascade_bwd.hip.
+#pragma once
+#include <vector>
+
+#include "rgp_grcn_plan.h"
+
+constexpr int kCt = 128;   // top-cell input channels: 64 upsampled + 1 saliency, zero-padded
+constexpr int kSt = 16;    // top-cell state channels: 3 units, zero-padded
+constexpr int kHp = 53;    // 49 + 2*2 halo for the 5x5 SAME convs
+constexpr int kN2 = 4864;  // 4802 FC outputs padded to a multiple of 128 (gradient rows)
+
+struct rgp_cascade {
+  int B = 0, T = 0, F = 0, dtype = RGP_BF16, image_hw = 98;
+  rgp_grcn* bottom = nullptr;
+  rgp_shallownet_t* shallow = nullptr;
+  std::vector<rgp::ConvDesc> up;             // 49 phases of the stride-7 transposed conv
+  rgp::ConvDesc xtop, zr, c, fc1, fc2;
+  std::vector<int> tab_pad53_t, tab_pad53_x;   // interior of a 53x53xkSt / 53x53xkCt image
+  size_t o_pad53_t = 0, o_pad53_x = 0;
+  size_t off_bottom = 0, off_shallow = 0, sal = 0, xtopbuf = 0, xpre = 0, hall = 0, u = 0, hp = 0, rh = 0, hrows = 0,
+         fcin = 0, mo1 = 0, b1i = 0, b2i = 0, ones = 0, zeros = 0, bn_id = 0;
+  int Kfc = 0, K2 = 0;
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  bool weights_set = false;
+
+  // ---- training (save_for_backward) ----
+  bool save = false;
+  // forward state kept for BPTT of the top cell: fp32 [T(+1)][B][2401][kSt]; operand images of every step
+  size_t hall_t = 0, uall = 0, rall = 0, call = 0;
+  size_t hp_all = 0;         // T  [B][T+1][53*53][kSt]   h_{t-1} of step t in slot (b, t); slot (b, 0) stays zero
+  size_t rhp_all = 0;        // T  [B][T][53*53][kSt]     r (.) h_{t-1}
+  size_t mask1 = 0, mask2 = 0;   // bytes [F][2401]: winning half of each maxout unit (0 = ReLU-gated)
+  // backward operands
+  rgp::ConvDesc b_fc2, b_fc1, b_tc, b_tzr, b_tx, b_up;   // input-gradient GEMMs / convs
+  std::vector<int> tab_pad53_64;                         // interior of a 53x53x64 image
+  size_t o_pad53_64 = 0;
+  size_t dz2 = 0, dz1 = 0;   // T  [F+1][kN2], row 0 zero: gradient w.r.t. the FC pre-activations (natural column order)
+  size_t dmo1 = 0, dfcin = 0;   // fp32 [F][K2] / [F][Kfc]
+  size_t dh_carry = 0, drh = 0; // fp32 [B][2401][kSt]
+  size_t dcp_pad = 0;        // T  [B][53*53][kSt]
+  size_t dzr_pad = 0;        // T  [B][53*53][2*kSt]
+  size_t dxpre_pad = 0;      // T  [F][53*53][64]: columns [dz_pre | dr_pre | dc_pre | 0]
+  size_t dup_pad = 0;        // T  [F][53*53][64]: gradient w.r.t. the upsampled maps
+  size_t d_hbn = 0;          // fp32 [F][49][256]: gradient w.r.t. the bottom states
+  size_t dwx = 0, dwh = 0, dwu = 0;   // fp32 scratch of the top cell's filter gradients in packed K order
+  size_t scratch_head = 0;   // fp32: dummy head / batch-norm gradients of the bottom sub-plan
+};
+
+// rgp_cascade_bwd.hip
+int cascade_bwd_plan(rgp_cascade* g, rgp::Arena& a);
+int cascade_bwd_upload(rgp_cascade* g, hipStream_t s);
+int cascade_bwd_pack(rgp_cascade* g, const rgp_cascade_weights* w, hipStream_t s);

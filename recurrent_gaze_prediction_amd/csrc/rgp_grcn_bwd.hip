@@ -73,7 +73,7 @@ int wgrad_gemm(const rgp_grcn* g, const T* AT, int rows, const T* BT, int N, lon
 
 template <typename T>
 int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const float* labels,
-                  const rgp_grcn_weights* gr, int loss_l2, hipStream_t s) {
+                  const rgp_grcn_weights* gr, int loss_l2, hipStream_t s, const float* ext_dy = nullptr) {
   GrcnBwd* b = g->bwd;
   char* ws = g->ws;
   const int B = g->B, T_ = g->T, S = g->S, P = g->P, F = g->F;
@@ -91,6 +91,14 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   RGP_HIP(hipMemsetAsync((void*)gr->up_weight2, 0, (size_t)25 * 32 * 64 * 4, s));
   RGP_HIP(hipMemsetAsync(ws + b->dgp.off, 0, b->dgp.bytes, s));
 
+  if (ext_dy) {
+    // the gradient w.r.t. the (batch-normalised) states comes from outside (cascade: the stride-7
+    // transposed conv above the bottom cell); the head of this plan is unused, its gradients are zero
+    RGP_HIP(hipMemcpyAsync(Fp(b->dy), ext_dy, (size_t)M * S * 4, hipMemcpyDeviceToDevice, s));
+    RGP_HIP(hipMemsetAsync((void*)gr->up_weight3, 0, (size_t)49 * 12 * 32 * 4, s));
+    RGP_HIP(hipMemsetAsync((void*)gr->out_W, 0, 12 * 4, s));
+    RGP_HIP(hipMemsetAsync((void*)gr->out_b, 0, 4, s));
+  } else {
   // 1. d loss / d logits, d out_b
   dlogits_kernel<<<F, 256, 0, s>>>(loss_l2 ? logits : probs, labels, Fp(b->dz), Fp(b->frame_sum), 2401, 1.0f / (float)F, loss_l2);
   sum_kernel<<<1, 256, 0, s>>>(Fp(b->frame_sum), (float*)gr->out_b, F, 1.0f);
@@ -118,6 +126,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     EpiParams e = make_epi(b->b_d1, Fp(b->dy), ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
   }
+  }  // !ext_dy
   // 5. per-timestep batch-norm
   const float inv = 1.0f / sqrtf(1.0f + 1e-3f);
   bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(Fp(b->dy), Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma,
@@ -361,6 +370,18 @@ int rgp_grcn_backward(rgp_grcn_t* g, const float* logits, const float* probs, co
   hipStream_t s = (hipStream_t)stream;
   return g->dtype == RGP_BF16 ? backward_impl<bf16_t>(g, probs, logits, labels, grads, loss_type, s)
                               : backward_impl<float>(g, probs, logits, labels, grads, loss_type, s);
+}
+
+int rgp_grcn_backward_from_states(rgp_grcn_t* g, const float* d_states, const rgp_grcn_weights* grads, rgp_stream_t stream) {
+  RGP_REQUIRE(g && d_states && grads, "rgp_grcn_backward_from_states: null argument");
+  if (!g->ws || !g->save || !g->bwd || !g->weights_set)
+    return set_err(RGP_ESTATE, "rgp_grcn_backward_from_states: needs a save_for_backward plan with weights and a forward");
+  const float* const* ptrs = (const float* const*)grads;
+  for (size_t i = 0; i < sizeof(rgp_grcn_weights) / sizeof(float*); ++i)
+    RGP_REQUIRE(ptrs[i], "rgp_grcn_backward_from_states: gradient pointer %zu is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? backward_impl<bf16_t>(g, nullptr, nullptr, nullptr, grads, 0, s, d_states)
+                              : backward_impl<float>(g, nullptr, nullptr, nullptr, grads, 0, s, d_states);
 }
 
 int rgp_grcn_backward_input(rgp_grcn_t* g, float* d_rows, rgp_stream_t stream) {

@@ -38,6 +38,7 @@ struct WgradParams {
   long long x_img_stride, y_img_stride;
   long long M;             // rows = images * Mw
   int Mw, N, nk, ldw;
+  int k_valid;             // rows of dW that exist (<= nk*BKE); the rest of the last chunk is channel padding
   int steps_per_split;     // 32-row steps per blockIdx.y
 };
 
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const long long k = (long long)kc * BKE + i * 16 + g * 4 + r;
-            atomicAdd(p.dW + k * p.ldw + n, acc[i][j][r]);
+            if (k < p.k_valid) atomicAdd(p.dW + k * p.ldw + n, acc[i][j][r]);
           }
         }
       }

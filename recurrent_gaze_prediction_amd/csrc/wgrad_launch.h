@@ -1,0 +1,40 @@
+// Host-side launch of wgrad_kernel: tiles of 4 K-chunks x 128 output channels, the row reduction split
+// over blockIdx.y so that about a thousand blocks are in flight.
+#pragma once
+#include <algorithm>
+
+#include "rgp_host.h"
+#include "wgrad.hip.h"
+
+namespace rgp {
+
+template <typename T, int G>
+int launch_wgrad(const WgradParams& p, hipStream_t s) {
+  auto kern = wgrad_kernel<T, G>;
+  constexpr int smem = WgradSmem<T>::BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  if (p.M <= 0 || p.nk <= 0 || p.N <= 0) return set_err(RGP_EINVAL, "wgrad: empty problem");
+  const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + 127) / 128;
+  const long long total_steps = (p.M + 31) / 32;
+  long long splits = std::max<long long>(1, 1024 / (n_kt * n_nt));
+  splits = std::min(splits, total_steps);
+  WgradParams q = p;
+  q.steps_per_split = (int)((total_steps + splits - 1) / splits);
+  splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
+  kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+// geometry helpers: rows of one image are the positions (z, y, x) of a D x H x W grid
+inline void wgrad_grid(WgradParams& p, int D, int H, int W) {
+  p.D = D; p.H = H; p.W = W;
+  p.inv_D = 1.0f / D; p.inv_H = 1.0f / H; p.inv_W = 1.0f / W;
+  p.Mw = D * H * W;
+}
+
+}  // namespace rgp

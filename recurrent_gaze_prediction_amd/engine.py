@@ -324,14 +324,16 @@ class CascadeEngine(object):
             ('fc1_w', 'LastProjection/fc1_w'), ('fc1_b', 'LastProjection/fc1_b'),
             ('fc2_w', 'LastProjection/fc2_w'), ('fc2_b', 'LastProjection/fc2_b'))
 
-    def __init__(self, batch, n_steps, image_hw=98, dtype='bf16', device='cuda:0'):
+    def __init__(self, batch, n_steps, image_hw=98, dtype='bf16', device='cuda:0', save_for_backward=False):
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.batch, self.n_steps, self.image_hw, self.dtype = int(batch), int(n_steps), int(image_hw), dtype
+        self.save_for_backward = bool(save_for_backward)
+        self.flat_params = self.flat_grads = self.grads = self.adam_m = self.adam_v = None
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.rgp_cascade_create(ctypes.byref(self._h), self.batch, self.n_steps, self.image_hw,
-                                                   _lib.DTYPES[dtype]))
+            _lib.check(self.lib.rgp_cascade_create_ex(ctypes.byref(self._h), self.batch, self.n_steps, self.image_hw,
+                                                      _lib.DTYPES[dtype], int(self.save_for_backward)))
             nbytes = self.lib.rgp_cascade_workspace_bytes(self._h)
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_cascade_bind_workspace(self._h, _ptr(self.workspace), nbytes,
@@ -343,18 +345,53 @@ class CascadeEngine(object):
         if h:
             self.lib.rgp_cascade_destroy(h)
 
-    def set_weights(self, params):
+    def _flat(self, shapes):
+        flat = torch.zeros(sum(int(np.prod(s)) for _, s in shapes), dtype=torch.float32, device=self.device)
+        views, off = {}, 0
+        for f, shp in shapes:
+            n = int(np.prod(shp))
+            views[f] = flat[off:off + n].view(shp)
+            off += n
+        return flat, views
+
+    def _struct(self, views):
         st = _lib.CascadeWeights()
-        w = {}
-        for field, key in self.KEYS:
-            w[field] = _as_dev_f32(params[key], self.device)
-            setattr(st, field, w[field].data_ptr())
+        for field, _ in self.KEYS:
+            setattr(st, field, views[field].data_ptr())
+        for k in _lib.ShallowNetWeights.FIELDS:                 # frozen (learning rate 0, base.py:264-265)
+            setattr(st.shallownet, k, self.weights['shallownet.' + k].data_ptr())
+        return st
+
+    def set_weights(self, params):
+        """The 19 trainable arrays live in one flat fp32 master buffer (one all-reduce bucket, one Adam launch);
+        the ShallowNet's arrays are separate and frozen."""
+        src = {field: _as_dev_f32(params[key], self.device) for field, key in self.KEYS}
+        if self.flat_params is None:
+            self.flat_params, self.weights = self._flat([(f, tuple(src[f].shape)) for f, _ in self.KEYS])
+        for f, _ in self.KEYS:
+            self.weights[f].copy_(src[f])
         for k in _lib.ShallowNetWeights.FIELDS:
-            w['shallownet.' + k] = _as_dev_f32(params['ShallowNet'][k], self.device)
-            setattr(st.shallownet, k, w['shallownet.' + k].data_ptr())
-        self.weights = w
+            self.weights['shallownet.' + k] = _as_dev_f32(params['ShallowNet'][k], self.device)
+        self.repack()
+
+    def repack(self):
+        st = self._struct(self.weights)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_cascade_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def backward(self, maps, gt, want_d_rows=False):
+        """Gradients of the l2 loss (gaze_grcn_cascade.py:428-441) after forward() on the same inputs.
+        Returns ({rgp_cascade_weights field: gradient view}, d_rows or None); the flat buffer is flat_grads."""
+        assert self.save_for_backward, 'create the engine with save_for_backward=True'
+        assert gt.is_cuda and gt.dtype == torch.float32 and gt.is_contiguous() and gt.numel() == maps.numel()
+        if self.flat_grads is None:
+            self.flat_grads, self.grads = self._flat([(f, tuple(self.weights[f].shape)) for f, _ in self.KEYS])
+        st = self._struct(self.grads)
+        d_rows = torch.empty(self.batch * self.n_steps * 49, 1024, device=self.device) if want_d_rows else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_cascade_backward(self._h, _ptr(maps), _ptr(gt), ctypes.byref(st), _ptr(d_rows),
+                                                     _stream_ptr(self.device)))
+        return self.grads, d_rows
 
     def forward(self, frame_images, c3d_input):
         """frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] fp32 device tensors -> maps [B,T,49,49]."""

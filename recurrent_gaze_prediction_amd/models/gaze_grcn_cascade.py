@@ -65,11 +65,25 @@ class _CascadeAdapter(object):
     def __init__(self, model):
         self.model = model
         self.net = CascadeEngine(model.batch_size, model.n_lstm_steps, getattr(model.config, 'image_hw', 98),
-                                 dtype=getattr(model.config, 'compute_dtype', 'bf16'), device=model.session.device)
+                                 dtype=getattr(model.config, 'compute_dtype', 'bf16'), device=model.session.device,
+                                 save_for_backward=getattr(model.config, 'trainable', True))
         self.frames = None
 
     def set_weights(self, params):
         self.net.set_weights(params)
+
+    # ---- training contract of GazePredictionGRU._train_op (backward -> all-reduce of flat_grads -> adam_step)
+    @property
+    def flat_grads(self):
+        return self.net.flat_grads
+
+    def backward(self, logits, probs, labels, loss_type='l2'):
+        assert loss_type == 'l2', 'the cascade is trained with the l2 loss (gaze_grcn_cascade.py:428-441)'
+        return self.net.backward(logits, labels.reshape(logits.shape).contiguous())[0]
+
+    def adam_step(self, step, lr, max_grad_norm=10.0):
+        from ..engine import adam_clip_step_multi
+        return adam_clip_step_multi([self.net], step, lr, max_grad_norm)
 
     def forward(self, c3d, want_probs=False):
         m = self.model
@@ -107,6 +121,9 @@ class GazePredictionGRCN(GazePredictionGRU):
         return engine
 
     def state_dict(self):
+        net = self.engine.net                      # the trained values live in the engine's master buffer
+        for field, key in net.KEYS:
+            self.variables[key] = net.weights[field].detach().cpu().numpy().copy()
         flat = {k: np.array(v, copy=True) for k, v in self.variables.items() if k != 'ShallowNet'}
         flat.update({'ShallowNet/' + k: np.array(v, copy=True) for k, v in self.variables['ShallowNet'].items()})
         return flat

@@ -63,6 +63,72 @@ def test_cascade_single_frame_and_second_call(gpu):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_cascade_backward_matches_autograd(gpu, dtype):
+    """rgp_cascade_backward: gradients of the l2 loss w.r.t. all 19 trainable arrays and w.r.t. the conv5b rows,
+    against torch autograd through the float64 CPU restatement (ShallowNet frozen, base.py:264-265)."""
+    from recurrent_gaze_prediction_amd.engine import CascadeEngine
+    B, T = 2, 3
+    p = syn.cascade_params(321)
+    rs = np.random.RandomState(322)
+    frames = rs.rand(B, T, 98, 98, 3).astype(np.float32)
+    c3d = syn.c3d_features(323, B, T)
+    gt, _ = syn.gaze_maps(324, B, T)
+    gt = (gt / gt.max()).astype(np.float32)                      # same scale as the maps
+    tp = to_t(p)
+    keys = [k for k in tp if k != 'ShallowNet']
+    for k in keys:
+        tp[k].requires_grad_(True)
+    x = torch.tensor(c3d, dtype=torch.float64, requires_grad=True)
+    maps_ref = torch_ref.cascade_forward(torch.tensor(frames, dtype=torch.float64), x, tp)
+    loss = torch_ref.gaze_loss(maps_ref, torch.tensor(gt, dtype=torch.float64), 'l2')
+    loss.backward()
+    eng = CascadeEngine(B, T, 98, dtype=dtype, device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    maps = eng.forward(torch.tensor(frames, device=gpu), torch.tensor(c3d, device=gpu))
+    assert rel_err(maps.cpu().numpy(), maps_ref.detach().numpy()) < TOL[dtype]['maps']
+    grads, d_rows = eng.backward(maps, torch.tensor(gt, device=gpu), want_d_rows=True)
+    # bf16: a rounded forward flips the ReLU / maxout gate of a few near-zero units, which moves single entries of
+    # the FC gradients by O(1) of their size; the RMS bound is the meaningful one there
+    tol_max, tol_rms = (1e-3, 3e-4) if dtype == 'f32' else (3e-1, 6e-2)
+    errs = {}
+    for field, key in CascadeEngine.KEYS:
+        ref = tp[key].grad.numpy()
+        got = grads[field].cpu().numpy().astype(np.float64)
+        assert np.abs(ref).max() > 0, key
+        errs[key] = (rel_err(got, ref), float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())))
+    bad = {k: e for k, e in errs.items() if not (e[0] < tol_max and e[1] < tol_rms)}
+    assert not bad, bad
+    ref_rows = x.grad.reshape(B * T, 512, 2, 49).permute(0, 3, 2, 1).reshape(B * T * 49, 1024).numpy()
+    assert rel_err(d_rows.cpu().numpy(), ref_rows) < (1e-3 if dtype == 'f32' else 1e-1)
+
+
+def test_cascade_training_through_the_model_api(gpu, tmp_path):
+    """single_step(train_mode=True) on the cascade class: l2 loss, backward, clipped TF-Adam; the loss on a fixed
+    validation batch goes down and the state dict carries the updated variables (ShallowNet unchanged)."""
+    from recurrent_gaze_prediction_amd.models.base import Session
+    from recurrent_gaze_prediction_amd.models.gaze_grcn_cascade import GazePredictionGRCN, GRUModelConfig
+    cfg = GRUModelConfig()
+    cfg.batch_size, cfg.n_lstm_steps, cfg.compute_dtype, cfg.train_dir, cfg.init_seed = 2, 2, 'bf16', str(tmp_path), 3
+    cfg.initial_learning_rate = 1e-3
+    ds = type('DS', (), {})()
+    ds.train = ds.valid = syn.SyntheticDataSet(8, 2, seed=5)
+    model = GazePredictionGRCN(Session(gpu), ds, cfg)
+    before = model.state_dict()
+    model.single_step(train_mode=False, dataset=syn.SyntheticDataSet(8, 2, seed=5))
+    loss0 = model.loss
+    np.random.seed(4)
+    for i in range(5):
+        assert model.single_step(train_mode=True) == i + 1
+    assert float(model.grad_norm.item()) > 0
+    model.single_step(train_mode=False, dataset=syn.SyntheticDataSet(8, 2, seed=5))
+    assert np.isfinite(model.loss) and model.loss < loss0, (loss0, model.loss)
+    after = model.state_dict()
+    assert not np.array_equal(after['LastProjection/fc2_w'], before['LastProjection/fc2_w'])
+    assert not np.array_equal(after['RCNBottom/GRU_Conv_U'], before['RCNBottom/GRU_Conv_U'])
+    assert np.array_equal(after['ShallowNet/fc1_w'], before['ShallowNet/fc1_w'])
+
+
 def test_cascade_model_class(gpu, tmp_path):
     """models.gaze_grcn_cascade.GazePredictionGRCN: predict / l2 loss / checkpoint round trip."""
     from recurrent_gaze_prediction_amd.models.base import Session
