@@ -84,6 +84,62 @@ class EndToEndGaze(object):
         return g
 
 
+class EndToEndCascade(object):
+    """BASELINE config 5 as a whole: video windows -> C3D -> two-level cascade (gaze_grcn_cascade.py) -> l2
+    loss, trained jointly (conv stack + every non-ShallowNet variable of the cascade)."""
+
+    def __init__(self, batch, n_steps, dtype='bf16', device='cuda:0', max_windows=None, seed=0, c3d_params=None,
+                 cascade_params=None, image_hw=98):
+        from .engine import CascadeEngine
+        self.B, self.T, self.F = int(batch), int(n_steps), int(batch) * int(n_steps)
+        self.device = torch.device(device)
+        self.c3d = C3DEngine(min(self.F, max_windows or self.F), dtype=dtype, device=device, save_for_backward=True)
+        self.head = CascadeEngine(self.B, self.T, image_hw, dtype=dtype, device=device, save_for_backward=True)
+        self.c3d.set_weights(c3d_params if c3d_params is not None else synthetic.c3d_params(seed))
+        self.head.set_weights(cascade_params if cascade_params is not None else synthetic.cascade_params(seed + 1, image_hw))
+        self.feats = torch.empty(self.F, 1024, 7, 7, device=self.device)
+        self.dist = None
+        self.global_step = 0
+
+    @property
+    def engines(self):
+        return [self.c3d, self.head]
+
+    def attach_process_group(self, dist):
+        self.dist = dist
+
+    def _chunks(self):
+        m = self.c3d.max_windows
+        return [(w0, min(m, self.F - w0)) for w0 in range(0, self.F, m)]
+
+    def forward(self, video, frames):
+        """video [B*T,16,112,112,3] fp32 (mean-subtracted), frames [B,T,H,W,3] fp32 in [0,1] -> maps [B,T,49,49]."""
+        for w0, n in self._chunks():
+            self.feats[w0:w0 + n] = self.c3d.forward(video[w0:w0 + n])[0]
+        return self.head.forward(frames, self.feats.reshape(self.B, self.T, 1024, 7, 7))
+
+    def backward(self, video, maps, labels):
+        labels = labels.reshape(maps.shape).contiguous()
+        loss = 0.5 * ((maps - labels) ** 2).sum() / float(self.F)
+        _, d_rows = self.head.backward(maps, labels, want_d_rows=True)
+        chunks = self._chunks()
+        self.c3d.flat_grads.zero_()
+        for w0, n in chunks:
+            if len(chunks) > 1:
+                self.c3d.forward(video[w0:w0 + n], want_features=False)
+            self.c3d.backward(d_rows=d_rows[w0 * 49:(w0 + n) * 49], zero_grads=False)
+        return loss
+
+    def train_step(self, video, frames, labels, lr, max_grad_norm=10.0):
+        maps = self.forward(video, frames)
+        loss = self.backward(video, maps, labels)
+        if self.dist is not None:
+            rdist.allreduce_mean_(self.dist, [self.head.flat_grads, self.c3d.flat_grads])
+        gnorm = adam_clip_step_multi(self.engines, self.global_step, lr, max_grad_norm)
+        self.global_step += 1
+        return loss, gnorm
+
+
 def flops_per_frame_train():
     """forward 77 426.06 MFLOP per frame (conv stack 76 993.27 + head 432.79); a trained layer
     costs 3x forward (fwd + dgrad + wgrad), conv1a has no dgrad."""

@@ -104,3 +104,26 @@ def test_train_steps_reduce_the_loss(gpu):
         assert np.isfinite(losses[-1]) and float(gnorm) > 0
     assert losses[-1] < losses[0], losses
     assert float((m.c3d.flat_params - w0).abs().max()) > 0 and float((m.head.flat_params - h0).abs().max()) > 0
+
+
+def test_config5_joint_training_steps(gpu):
+    """C3D + cascade trained jointly (BASELINE config 5): finite steps, falling l2 loss, all three parameter groups
+    (conv stack, cascade, frozen ShallowNet) behave as the reference's train op prescribes."""
+    from recurrent_gaze_prediction_amd.finetune import EndToEndCascade
+    B, T = 1, 2
+    m = EndToEndCascade(B, T, dtype='bf16', device=gpu, seed=11)
+    rs = np.random.RandomState(81)
+    v = torch.tensor((rs.rand(B * T, 16, 112, 112, 3).astype(np.float32) - 0.5) * 2, device=gpu)
+    fr = torch.tensor(rs.rand(B, T, 98, 98, 3).astype(np.float32), device=gpu)
+    gt, _ = syn.gaze_maps(82, B, T)
+    lab = torch.tensor((gt / gt.max()).astype(np.float32), device=gpu)
+    w0, h0 = m.c3d.flat_params.clone(), m.head.flat_params.clone()
+    s0 = m.head.weights['shallownet.fc1_w'].clone()
+    losses = []
+    for _ in range(5):
+        loss, gnorm = m.train_step(v, fr, lab, lr=1e-3)
+        losses.append(float(loss))
+        assert np.isfinite(losses[-1]) and float(gnorm) > 0
+    assert losses[-1] < losses[0], losses
+    assert float((m.c3d.flat_params - w0).abs().max()) > 0 and float((m.head.flat_params - h0).abs().max()) > 0
+    assert torch.equal(m.head.weights['shallownet.fc1_w'], s0)
