@@ -175,6 +175,14 @@ int rgp_fcgru_set_weights(rgp_fcgru_t* plan, const rgp_fcgru_weights* w, rgp_str
 /* c3d_input [B,T,1024,7,7] -> logits [B,T,GH,GW]; probs (optional) = per-frame softmax. */
 int rgp_fcgru_forward(rgp_fcgru_t* plan, const float* c3d_input, float* logits, float* probs, rgp_stream_t stream);
 
+/* Training (config 2): a plan created with save_for_backward = 1 keeps the gates and operand rows of every step;
+ * rgp_fcgru_backward then differentiates the loss of gaze_rnn.py:363-408 (loss_type 0 xentropy, 1 l2) w.r.t.
+ * all eight variables (grads: arrays shaped like the weights, fully overwritten), as rgp_grcn_backward does. */
+int rgp_fcgru_create_ex(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_h, int gazemap_w, int dtype,
+                        int save_for_backward);
+int rgp_fcgru_backward(rgp_fcgru_t* plan, const float* logits, const float* probs, const float* labels,
+                       const rgp_fcgru_weights* grads, int loss_type, rgp_stream_t stream);
+
 /* ------------------------------------------------------------------ frame-wise ShallowNet */
 typedef struct rgp_shallownet rgp_shallownet_t;
 

@@ -1,22 +1,25 @@
-// librgp_hip.so: the fully-connected GRU gaze model (BASELINE config 2).
+// librgp_hip.so: the fully-connected GRU gaze model (BASELINE config 2), forward and backward.
 // Reference graph: /root/reference/models/gaze_rnn.py:211-360 (GazePredictionGRU.
 // create_gazeprediction_network): 1024->32 projection per pixel, flatten to 1568,
 // tf rnn_cell.GRUCell(1617) over T steps, 1617 -> GH*GW output projection.
 // TF-1.x GRUCell:  [r,u] = sigmoid([x,h] Wg + bg);  c = tanh([x, r*h] Wc + bc);
 //                  h' = u*h + (1-u)*c.
 //
-// Nothing new on the device: every contraction is igemm_kernel in plain-GEMM form (one row
-// per "image"), the x-parts of both kernels are hoisted over all T steps, and the gate math
+// Nothing new on the device for the forward: every contraction is igemm_kernel in plain-GEMM form (one
+// row per "image"), the x-parts of both kernels are hoisted over all T steps, and the gate math
 // is the ConvGRU epilogue pair (EpiGruZR / EpiGruC) with the gate columns packed as [u | r]
 // and an identity "batch-norm".  All K / N extents are zero-padded to multiples of 64.
+// Backward (tf.gradients of the loss of gaze_rnn.py:363-408, base.py:278-281): BPTT with two input-gradient
+// GEMMs per step; every weight gradient is hoisted over all T steps and computed by wgrad_kernel
+// (rows = frames, transposing LDS reads) on the operand rows the forward kept.
 #include <algorithm>
 
-#include "rgp_host.h"
+#include "wgrad_launch.h"
 
 using namespace rgp;
 
 struct rgp_fcgru {
-  int B = 0, T = 0, F = 0, G = 0, dtype = RGP_F32;
+  int B = 0, T = 0, F = 0, G = 0, Gp = 0, dtype = RGP_F32;
   int Cp = 32, nx = 1568, n = 1617, Kx = 0, np = 0;
   ConvDesc proj, xg, zr, c, out;
   size_t o_zero1 = 0, o_lin = 0;
@@ -25,6 +28,17 @@ struct rgp_fcgru {
   char* ws = nullptr;
   bool weights_set = false;
   const float *proj_b = nullptr, *out_b = nullptr;
+  // ---- training ----
+  bool save = false;
+  size_t hall_t = 0, uall = 0, rall = 0, call = 0;   // fp32 [T(+1)][B][np]
+  size_t hp_all = 0, rh_all = 0;                      // T [B][T+1][np] (h_{t-1} of step t in slot (b,t)) / [B][T][np]
+  ConvDesc b_out, b_c, b_zr, b_x;                     // input-gradient GEMMs over the transposed kernels
+  size_t dzo = 0;                                     // T [F+1][Gp]   d loss / d logits, row 0 zero
+  size_t dh_head = 0, carry = 0, drh = 0;             // fp32 [F][np], [B][np], [B][np]
+  size_t dcp = 0, dzr = 0;                            // T [B][np], [B][2np]
+  size_t dxpre = 0;                                   // T [F+1][3np]  [du_pre | dr_pre | dc_pre], row 0 zero
+  size_t dE = 0;                                      // T [F+1][Kx]   row 0 zero
+  size_t dwx = 0, dwh = 0, dwc = 0;                   // fp32 [Kx][3np], [np][2np], [np][np]
 };
 
 namespace {
@@ -64,6 +78,21 @@ int set_weights_impl(rgp_fcgru* g, const rgp_fcgru_weights* w, hipStream_t s) {
   RGP_HIP(hipMemcpyAsync(xb + 2 * np, w->candidate_bias, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   g->proj_b = w->proj_c3d_b;
   g->out_b = w->proj_out_b;
+  if (g->save) {
+    // transposed kernels for the input gradients: packed row = the GEMM's output unit, K = the gradient's columns
+    for (ConvDesc* d : {&g->b_out, &g->b_c, &g->b_zr, &g->b_x}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
+    auto pkT = [&](ConvDesc& d, const float* src, long long row_stride, int cols, int rows, int k0) -> int {
+      d.s_tap = 0; d.s_n = row_stride; d.s_c = 1; d.cin_src = cols;
+      return pack_filter<T>(d, src, ws, rows, 0, s, k0, 1);
+    };
+    RGP_TRY(pkT(g->b_out, w->proj_out_W, g->G, g->G, n, 0));                                        // d h = d logits Wout^T
+    RGP_TRY(pkT(g->b_c, w->candidate_kernel + (long long)nx * n, n, n, n, 0));                      // d(r.h) = dc_pre Wc_h^T
+    RGP_TRY(pkT(g->b_zr, w->gates_kernel + (long long)nx * 2 * n + n, 2LL * n, n, n, 0));           // carry += du_pre Wu_h^T
+    RGP_TRY(pkT(g->b_zr, w->gates_kernel + (long long)nx * 2 * n, 2LL * n, n, n, np));              //        + dr_pre Wr_h^T
+    RGP_TRY(pkT(g->b_x, w->gates_kernel + n, 2LL * n, n, nx, 0));                                   // d E = [du|dr|dc]_pre Wx^T
+    RGP_TRY(pkT(g->b_x, w->gates_kernel, 2LL * n, n, nx, np));
+    RGP_TRY(pkT(g->b_x, w->candidate_kernel, n, n, nx, 2 * np));
+  }
   g->weights_set = true;
   return RGP_OK;
 }
@@ -77,6 +106,7 @@ template <typename T>
 int forward_impl(rgp_fcgru* g, const float* c3d_input, float* logits, float* probs, hipStream_t s) {
   char* ws = g->ws;
   const int B = g->B, T_ = g->T, F = g->F, np = g->np;
+  const bool save = g->save;
   nchw_to_rows_kernel<T><<<dim3(1024 / 64, F), 256, 0, s>>>(c3d_input, (T*)(ws + g->xt), 1024);
   RGP_HIP(hipGetLastError());
   {  // per-pixel projection, rows of the x-GEMM (gaze_rnn.py:294-308, flatten :340-341)
@@ -92,25 +122,34 @@ int forward_impl(rgp_fcgru* g, const float* c3d_input, float* logits, float* pro
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, true, false>>(p, e, s)));
   }
   const size_t st = (size_t)B * np;
-  RGP_HIP(hipMemsetAsync(ws + g->hp, 0, st * sizeof(T), s));
-  RGP_HIP(hipMemsetAsync(ws + g->hall, 0, st * 4, s));
-  float* hall = (float*)(ws + g->hall);
+  if (!save) RGP_HIP(hipMemsetAsync(ws + g->hp, 0, st * sizeof(T), s));
+  float* hall = (float*)(ws + (save ? g->hall_t : g->hall));
+  RGP_HIP(hipMemsetAsync(hall, 0, st * 4, s));
   for (int t = 0; t < T_; ++t) {
-    EpiParams e = make_epi(g->zr, ws + g->rh, ws);
+    // training keeps every step's states, gates and operand rows (slot (b, 0) of hp_all is never written = h_0)
+    char* hp_in = save ? ws + g->hp_all + (size_t)t * np * sizeof(T) : ws + g->hp;
+    char* hp_out = save ? ws + g->hp_all + (size_t)(t + 1) * np * sizeof(T) : ws + g->hp;
+    char* rh_buf = save ? ws + g->rh_all + (size_t)t * np * sizeof(T) : ws + g->rh;
+    const long long hp_stride = save ? (long long)(T_ + 1) * np : np, rh_stride = save ? (long long)T_ * np : np;
+    EpiParams e = make_epi(g->zr, rh_buf, ws);
+    e.out_img_stride = rh_stride;
     e.xpre = (const float*)(ws + g->xpre) + (size_t)t * 3 * np;
     e.xpre_img_stride = (long long)T_ * 3 * np;
     e.xpre_ld = 3 * np;
     e.xpre_col = 0;
     e.S = np;
     e.state_rows = 1;
-    e.h_prev = hall + (size_t)(t & 1) * st;
-    e.h_next = hall + (size_t)((t + 1) & 1) * st;
-    e.u_gate = (float*)(ws + g->u);
-    IgemmParams p = make_params(g->zr, ws + g->hp, ws, B);
+    e.h_prev = hall + (size_t)(save ? t : (t & 1)) * st;
+    e.h_next = hall + (size_t)(save ? t + 1 : ((t + 1) & 1)) * st;
+    e.u_gate = save ? (float*)(ws + g->uall) + (size_t)t * st : (float*)(ws + g->u);
+    e.r_save = save ? (float*)(ws + g->rall) + (size_t)t * st : nullptr;
+    e.c_save = save ? (float*)(ws + g->call) + (size_t)t * st : nullptr;
+    IgemmParams p = make_params(g->zr, hp_in, ws, B);
+    p.in_img_stride = hp_stride;
     RGP_TRY((launch_igemm<T, 1, 1, EpiGruZR<T>>(p, e, s)));
-    e.out = ws + g->hp;
+    e.out = hp_out;
     e.out_tab = (const int*)(ws + g->c.out_tab_off);
-    e.out_img_stride = g->c.out_img_stride;
+    e.out_img_stride = hp_stride;
     e.xpre_col = 2 * np;
     e.out2 = ws + g->hrows;
     e.out2_tab = (const int*)(ws + g->c.out_tab_off);
@@ -120,7 +159,8 @@ int forward_impl(rgp_fcgru* g, const float* c3d_input, float* logits, float* pro
     e.bn_gamma = (const float*)(ws + g->ones);
     e.bn_beta = (const float*)(ws + g->zeros);
     e.bn_inv_std = 1.0f;
-    IgemmParams pc = make_params(g->c, ws + g->rh, ws, B);
+    IgemmParams pc = make_params(g->c, rh_buf, ws, B);
+    pc.in_img_stride = rh_stride;
     RGP_TRY((launch_igemm<T, 1, 1, EpiGruC<T>>(pc, e, s)));
   }
   {  // output projection (gaze_rnn.py:346-349)
@@ -133,17 +173,221 @@ int forward_impl(rgp_fcgru* g, const float* c3d_input, float* logits, float* pro
   return RGP_OK;
 }
 
+// ---------------------------------------------------------------- backward kernels
+// d loss / d logits (gaze_rnn.py:363-408): xentropy (probs - labels) / F, l2 (logits - labels) / F
+template <typename T>
+__global__ __launch_bounds__(256) void fc_dlogits_kernel(const float* __restrict__ a, const float* __restrict__ labels, float scale,
+                                                         T* __restrict__ dzo, int G, int Gp, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int gcol = (int)(i % G);
+    const long long f = i / G;
+    dzo[(f + 1) * Gp + gcol] = Elem<T>::to((a[i] - labels[i]) * scale);
+  }
+}
+
+// out[c] = sum over rows of base[row*row_stride + c*col_stride]: bias gradients (one thread per column)
+template <typename T>
+__global__ void fc_colsum_kernel(const T* __restrict__ base, long long row_stride, long long rows, int ncols, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float a = 0.f;
+  for (long long r = 0; r < rows; ++r) a += Elem<T>::from(base[r * row_stride + c]);
+  out[c] = a;
+}
+
+// BPTT step (GRUCell differentiated), part 1 / part 2: see top_bwd{1,2}_kernel of the cascade for the algebra
+template <typename T>
+__global__ __launch_bounds__(256) void fc_bwd1_kernel(const float* __restrict__ dh_head, float* __restrict__ carry,
+                                                      const float* __restrict__ h_prev, const float* __restrict__ u,
+                                                      const float* __restrict__ c, T* __restrict__ dxpre, T* __restrict__ dcp,
+                                                      int B, int T_, int t, int np, int first) {
+  const long long total = (long long)B * np;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i % np);
+    const long long f = (i / np) * T_ + t;
+    const float dh = dh_head[f * np + j] + (first ? 0.f : carry[i]);
+    const float uu = u[i], cc = c[i];
+    const float du = dh * (h_prev[i] - cc), dc = dh * (1.f - uu);
+    carry[i] = dh * uu;
+    const T dcp_t = Elem<T>::to(dc * (1.f - cc * cc));
+    T* row = dxpre + (f + 1) * 3 * np;
+    row[j] = Elem<T>::to(du * uu * (1.f - uu));
+    row[2 * np + j] = dcp_t;
+    dcp[i] = dcp_t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fc_bwd2_kernel(const float* __restrict__ drh, float* __restrict__ carry,
+                                                      const float* __restrict__ h_prev, const float* __restrict__ r,
+                                                      T* __restrict__ dxpre, T* __restrict__ dzr, int B, int T_, int t, int np) {
+  const long long total = (long long)B * np;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i % np);
+    const long long b = i / np, f = b * T_ + t;
+    const float d = drh[i], rr = r[i];
+    carry[i] += d * rr;
+    const T drp = Elem<T>::to(d * h_prev[i] * rr * (1.f - rr));
+    T* row = dxpre + (f + 1) * 3 * np;
+    row[np + j] = drp;
+    dzr[b * 2 * np + j] = row[j];
+    dzr[b * 2 * np + np + j] = drp;
+  }
+}
+
+// packed gradients -> the TF kernels: gates_kernel [nx+n, 2n] columns [r | u], candidate_kernel [nx+n, n]
+__global__ __launch_bounds__(256) void fc_unpack_kernel(const float* __restrict__ dwx, const float* __restrict__ dwh,
+                                                        const float* __restrict__ dwc, float* __restrict__ gates,
+                                                        float* __restrict__ cand, int nx, int n, int np) {
+  const long long total = (long long)(nx + n) * n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i % n);
+    const int k = (int)(i / n);
+    if (k < nx) {
+      const float* row = dwx + (long long)k * 3 * np;
+      gates[(long long)k * 2 * n + j] = row[np + j];
+      gates[(long long)k * 2 * n + n + j] = row[j];
+      cand[i] = row[2 * np + j];
+    } else {
+      const float* row = dwh + (long long)(k - nx) * 2 * np;
+      gates[(long long)k * 2 * n + j] = row[np + j];
+      gates[(long long)k * 2 * n + n + j] = row[j];
+      cand[i] = dwc[(long long)(k - nx) * np + j];
+    }
+  }
+}
+
+template <typename T>
+int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const float* labels, const rgp_fcgru_weights* gr,
+                  int loss_l2, hipStream_t s) {
+  char* ws = g->ws;
+  const int B = g->B, T_ = g->T, F = g->F, np = g->np, n = g->n, nx = g->nx, Kx = g->Kx, G = g->G, Gp = g->Gp;
+  auto Tp = [&](size_t off) { return (T*)(ws + off); };
+  auto Fp = [&](size_t off) { return (float*)(ws + off); };
+  auto nblk = [](long long x) { return (int)std::min<long long>((x + 255) / 256, 8192); };
+  const size_t st = (size_t)B * np;
+  // 1. loss layer and output projection
+  fc_dlogits_kernel<T><<<nblk((long long)F * G), 256, 0, s>>>(loss_l2 ? logits : probs, labels, 1.0f / (float)F, Tp(g->dzo), G, Gp,
+                                                             (long long)F * G);
+  fc_colsum_kernel<T><<<(G + 255) / 256, 256, 0, s>>>(Tp(g->dzo) + Gp, Gp, F, G, (float*)gr->proj_out_b);
+  RGP_HIP(hipGetLastError());
+  WgradParams wp;
+  auto rows_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, const void* dY, int ldy, int y_col, int N, float* dW, int ldw,
+                        int k_valid) -> int {
+    RGP_HIP(hipMemsetAsync(dW, 0, (size_t)k_valid * ldw * 4, s));
+    memset(&wp, 0, sizeof(wp));
+    wp.X = X; wp.dY = dY; wp.dW = dW;
+    wgrad_grid(wp, 1, 1, F);
+    wp.x_sx = ldx; wp.y_sx = ldy; wp.y_org = ldy + y_col;
+    wp.koff = (const int*)(ws + fwd.koff_off);
+    wp.M = F; wp.N = N; wp.nk = fwd.nk; wp.ldw = ldw; wp.k_valid = k_valid;
+    return launch_wgrad<T, 1>(wp, s);
+  };
+  RGP_TRY(rows_wgrad(ws + g->hrows, np, g->out, ws + g->dzo, Gp, 0, G, (float*)gr->proj_out_W, G, n));
+  {
+    IgemmParams p = make_params(g->b_out, Tp(g->dzo) + Gp, ws, F);
+    EpiParams e = make_epi(g->b_out, Fp(g->dh_head), ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+  }
+  // 2. BPTT
+  const float* hall = Fp(g->hall_t);
+  for (int t = T_ - 1; t >= 0; --t) {
+    const float* h_prev = hall + (size_t)t * st;
+    fc_bwd1_kernel<T><<<nblk((long long)st), 256, 0, s>>>(Fp(g->dh_head), Fp(g->carry), h_prev, Fp(g->uall) + (size_t)t * st,
+                                                         Fp(g->call) + (size_t)t * st, Tp(g->dxpre), Tp(g->dcp), B, T_, t, np, t == T_ - 1);
+    RGP_HIP(hipGetLastError());
+    {
+      IgemmParams p = make_params(g->b_c, Tp(g->dcp), ws, B);
+      EpiParams e = make_epi(g->b_c, Fp(g->drh), ws);
+      RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+    }
+    fc_bwd2_kernel<T><<<nblk((long long)st), 256, 0, s>>>(Fp(g->drh), Fp(g->carry), h_prev, Fp(g->rall) + (size_t)t * st, Tp(g->dxpre),
+                                                         Tp(g->dzr), B, T_, t, np);
+    RGP_HIP(hipGetLastError());
+    {
+      IgemmParams p = make_params(g->b_zr, Tp(g->dzr), ws, B);
+      EpiParams e = make_epi(g->b_zr, Fp(g->carry), ws);
+      RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
+    }
+  }
+  // 3. kernel gradients, hoisted over all steps
+  RGP_TRY(rows_wgrad(ws + g->E, Kx, g->xg, ws + g->dxpre, 3 * np, 0, 3 * np, Fp(g->dwx), 3 * np, Kx));
+  {
+    RGP_HIP(hipMemsetAsync(Fp(g->dwh), 0, (size_t)np * 2 * np * 4, s));
+    memset(&wp, 0, sizeof(wp));
+    wp.X = ws + g->hp_all; wp.dY = ws + g->dxpre; wp.dW = Fp(g->dwh);
+    wgrad_grid(wp, T_, 1, 1);                                   // image = clip b, z = step t
+    wp.x_sz = np; wp.x_img_stride = (long long)(T_ + 1) * np;
+    wp.y_sz = 3 * np; wp.y_img_stride = (long long)T_ * 3 * np; wp.y_org = 3 * np;
+    wp.koff = (const int*)(ws + g->zr.koff_off);
+    wp.M = F; wp.N = 2 * np; wp.nk = g->zr.nk; wp.ldw = 2 * np; wp.k_valid = np;
+    RGP_TRY((launch_wgrad<T, 1>(wp, s)));
+    RGP_HIP(hipMemsetAsync(Fp(g->dwc), 0, (size_t)np * np * 4, s));
+    wp.X = ws + g->rh_all; wp.dW = Fp(g->dwc);
+    wp.x_img_stride = (long long)T_ * np;
+    wp.y_org = 3 * np + 2 * np;
+    wp.koff = (const int*)(ws + g->c.koff_off);
+    wp.N = np; wp.nk = g->c.nk; wp.ldw = np;
+    RGP_TRY((launch_wgrad<T, 1>(wp, s)));
+  }
+  fc_unpack_kernel<<<nblk((long long)(nx + n) * n), 256, 0, s>>>(Fp(g->dwx), Fp(g->dwh), Fp(g->dwc), (float*)gr->gates_kernel,
+                                                               (float*)gr->candidate_kernel, nx, n, np);
+  // biases: gates_bias [r | u], candidate_bias
+  const T* dx1 = Tp(g->dxpre) + 3 * np;
+  fc_colsum_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(dx1 + np, 3LL * np, F, n, (float*)gr->gates_bias);
+  fc_colsum_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(dx1, 3LL * np, F, n, (float*)gr->gates_bias + n);
+  fc_colsum_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(dx1 + 2 * np, 3LL * np, F, n, (float*)gr->candidate_bias);
+  RGP_HIP(hipGetLastError());
+  // 4. projection: d E = dxpre Wx^T, then per-pixel rows [F*49][32]
+  {
+    IgemmParams p = make_params(g->b_x, dx1, ws, F);
+    EpiParams e = make_epi(g->b_x, Tp(g->dE) + Kx, ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+  }
+  {
+    RGP_HIP(hipMemsetAsync((void*)gr->proj_c3d_W, 0, (size_t)1024 * g->Cp * 4, s));
+    memset(&wp, 0, sizeof(wp));
+    wp.X = ws + g->xt; wp.dY = ws + g->dE; wp.dW = (float*)gr->proj_c3d_W;
+    wgrad_grid(wp, 1, 1, 49);                                   // image = frame, 49 pixel rows
+    wp.x_sx = 1024; wp.x_img_stride = 49LL * 1024;
+    wp.y_sx = g->Cp; wp.y_img_stride = Kx; wp.y_org = Kx;
+    wp.koff = (const int*)(ws + g->proj.koff_off);
+    wp.M = (long long)F * 49; wp.N = g->Cp; wp.nk = g->proj.nk; wp.ldw = g->Cp; wp.k_valid = 1024;
+    RGP_TRY((launch_wgrad<T, 1>(wp, s)));
+    // bias: sum over frames and pixels = column sums of the [F*49][32] view; rows are 32 apart inside a frame row
+    // of Kx, so sum per frame-row column first: c3d_b[c] = sum_f sum_pix dE[f][pix*32 + c]
+    fc_colsum_kernel<T><<<(Kx + 255) / 256, 256, 0, s>>>(Tp(g->dE) + Kx, Kx, F, Kx, Fp(g->dwc));     // dwc reused as [Kx] scratch
+    RGP_HIP(hipGetLastError());
+  }
+  return RGP_OK;
+}
+
+// proj_c3d_b[c] = sum_pix colsum[pix*32 + c]
+__global__ void fc_fold_bias_kernel(const float* __restrict__ colsum, float* __restrict__ out, int Cp) {
+  const int c = threadIdx.x;
+  if (c >= Cp) return;
+  float a = 0.f;
+  for (int p = 0; p < 49; ++p) a += colsum[p * Cp + c];
+  out[c] = a;
+}
+
 }  // namespace
 
 extern "C" {
 
 int rgp_fcgru_create(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_h, int gazemap_w, int dtype) {
+  return rgp_fcgru_create_ex(plan, batch, n_steps, gazemap_h, gazemap_w, dtype, 0);
+}
+
+int rgp_fcgru_create_ex(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_h, int gazemap_w, int dtype, int save_for_backward) {
   RGP_REQUIRE(plan && batch > 0 && n_steps > 0, "rgp_fcgru_create: bad arguments");
   RGP_REQUIRE((gazemap_h == 49 && gazemap_w == 49) || (gazemap_h == 7 && gazemap_w == 7),
               "rgp_fcgru_create: gaze map %dx%d (reference uses 49x49 or 7x7)", gazemap_h, gazemap_w);
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_fcgru_create: dtype %d", dtype);
   rgp_fcgru* g = new rgp_fcgru();
   g->B = batch; g->T = n_steps; g->F = batch * n_steps; g->G = gazemap_h * gazemap_w; g->dtype = dtype;
+  g->save = save_for_backward != 0;
+  g->Gp = (int)align_up(g->G, 128);
   g->Kx = (int)align_up(g->nx, 64);
   g->np = (int)align_up(g->n, 64);
   const int es = esize(dtype), F = g->F, np = g->np, Kx = g->Kx;
@@ -168,6 +412,31 @@ int rgp_fcgru_create(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_h, 
   g->xbias = a.take((size_t)3 * np * 4);
   g->ones = a.take((size_t)np * 4);
   g->zeros = a.take((size_t)np * 4);
+  if (g->save) {
+    const size_t st = (size_t)batch * np;
+    gemm_desc(g->b_out, np, g->Gp, g->Gp, np, dtype);
+    gemm_desc(g->b_c, np, np, np, np, dtype);
+    gemm_desc(g->b_zr, np, 2 * np, 2LL * np, np, dtype);
+    gemm_desc(g->b_x, Kx, 3 * np, 3LL * np, Kx, dtype);
+    for (ConvDesc* d : {&g->b_out, &g->b_c, &g->b_zr, &g->b_x}) d->reserve(a, dtype);
+    g->hall_t = a.take((size_t)(n_steps + 1) * st * 4);
+    g->uall = a.take((size_t)n_steps * st * 4);
+    g->rall = a.take((size_t)n_steps * st * 4);
+    g->call = a.take((size_t)n_steps * st * 4);
+    g->hp_all = a.take((size_t)batch * (n_steps + 1) * np * es + 1024);
+    g->rh_all = a.take((size_t)F * np * es + 1024);
+    g->dzo = a.take((size_t)(F + 1) * g->Gp * es + 1024);
+    g->dh_head = a.take((size_t)F * np * 4);
+    g->carry = a.take(st * 4);
+    g->drh = a.take(st * 4);
+    g->dcp = a.take(st * es);
+    g->dzr = a.take(2 * st * es);
+    g->dxpre = a.take((size_t)(F + 1) * 3 * np * es + 1024);
+    g->dE = a.take((size_t)(F + 1) * Kx * es + 1024);
+    g->dwx = a.take((size_t)Kx * 3 * np * 4);
+    g->dwh = a.take((size_t)np * 2 * np * 4);
+    g->dwc = a.take((size_t)np * np * 4);
+  }
   g->ws_bytes = a.off;
   *plan = g;
   return RGP_OK;
@@ -189,6 +458,7 @@ int rgp_fcgru_bind_workspace(rgp_fcgru_t* g, void* workspace, size_t bytes, rgp_
   g->weights_set = false;
   RGP_HIP(hipMemsetAsync(g->ws, 0, g->ws_bytes, s));
   for (ConvDesc* d : {&g->proj, &g->xg, &g->zr, &g->c, &g->out}) RGP_TRY(upload_desc(*d, g->ws, s));
+  if (g->save) for (ConvDesc* d : {&g->b_out, &g->b_c, &g->b_zr, &g->b_x}) RGP_TRY(upload_desc(*d, g->ws, s));
   fill_kernel<<<(g->np + 255) / 256, 256, 0, s>>>((float*)(g->ws + g->ones), 1.0f, g->np);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
@@ -211,6 +481,24 @@ int rgp_fcgru_forward(rgp_fcgru_t* g, const float* c3d_input, float* logits, flo
   hipStream_t s = (hipStream_t)stream;
   return g->dtype == RGP_BF16 ? forward_impl<bf16_t>(g, c3d_input, logits, probs, s)
                               : forward_impl<float>(g, c3d_input, logits, probs, s);
+}
+
+int rgp_fcgru_backward(rgp_fcgru_t* g, const float* logits, const float* probs, const float* labels,
+                       const rgp_fcgru_weights* grads, int loss_type, rgp_stream_t stream) {
+  RGP_REQUIRE(g && logits && labels && grads, "rgp_fcgru_backward: null argument");
+  if (!g->save) return set_err(RGP_ESTATE, "rgp_fcgru_backward: plan was created without save_for_backward");
+  if (!g->ws || !g->weights_set) return set_err(RGP_ESTATE, "rgp_fcgru_backward: workspace/weights not set");
+  RGP_REQUIRE(loss_type == 0 || loss_type == 1, "rgp_fcgru_backward: loss_type %d (0 xentropy, 1 l2)", loss_type);
+  RGP_REQUIRE(loss_type == 1 || probs, "rgp_fcgru_backward: xentropy needs the softmax maps");
+  const float* const* ptrs = (const float* const*)grads;
+  for (size_t i = 0; i < sizeof(rgp_fcgru_weights) / sizeof(float*); ++i)
+    RGP_REQUIRE(ptrs[i], "rgp_fcgru_backward: gradient pointer %zu is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  RGP_TRY(g->dtype == RGP_BF16 ? backward_impl<bf16_t>(g, logits, probs, labels, grads, loss_type, s)
+                               : backward_impl<float>(g, logits, probs, labels, grads, loss_type, s));
+  fc_fold_bias_kernel<<<1, 64, 0, s>>>((const float*)(g->ws + g->dwc), (float*)grads->proj_c3d_b, g->Cp);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
 }
 
 }  // extern "C"

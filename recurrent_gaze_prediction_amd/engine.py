@@ -226,15 +226,17 @@ def softmax_xent(logits, labels=None, want_probs=True):
 class FcGruEngine(object):
     """fc-GRU gaze model (models/gaze_rnn.py:211-360, BASELINE config 2) at fixed (B, T, GH, GW)."""
 
-    def __init__(self, batch, n_steps, gazemap_hw=(49, 49), dtype='f32', device='cuda:0'):
+    def __init__(self, batch, n_steps, gazemap_hw=(49, 49), dtype='f32', device='cuda:0', save_for_backward=False):
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.B, self.T, self.GH, self.GW = int(batch), int(n_steps), int(gazemap_hw[0]), int(gazemap_hw[1])
         self.dtype = dtype
+        self.save_for_backward = bool(save_for_backward)
+        self.flat_params = self.flat_grads = self.grads = self.adam_m = self.adam_v = None
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.rgp_fcgru_create(ctypes.byref(self._h), self.B, self.T, self.GH, self.GW,
-                                                 _lib.DTYPES[dtype]))
+            _lib.check(self.lib.rgp_fcgru_create_ex(ctypes.byref(self._h), self.B, self.T, self.GH, self.GW,
+                                                    _lib.DTYPES[dtype], int(self.save_for_backward)))
             nbytes = self.lib.rgp_fcgru_workspace_bytes(self._h)
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_fcgru_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
@@ -245,14 +247,50 @@ class FcGruEngine(object):
         if h:
             self.lib.rgp_fcgru_destroy(h)
 
-    def set_weights(self, params):
-        w = {k: _as_dev_f32(params[k], self.device) for k in _lib.FcGruWeights.FIELDS}
+    def _flat(self, like):
+        sizes = [(k, tuple(like[k].shape)) for k in _lib.FcGruWeights.FIELDS]
+        flat = torch.zeros(sum(int(np.prod(s)) for _, s in sizes), dtype=torch.float32, device=self.device)
+        views, off = {}, 0
+        for k, shp in sizes:
+            n = int(np.prod(shp))
+            views[k] = flat[off:off + n].view(shp)
+            off += n
+        return flat, views
+
+    def _struct(self, views):
         st = _lib.FcGruWeights()
         for k in _lib.FcGruWeights.FIELDS:
-            setattr(st, k, w[k].data_ptr())
-        self.weights = w
+            setattr(st, k, views[k].data_ptr())
+        return st
+
+    def set_weights(self, params):
+        src = {k: _as_dev_f32(params[k], self.device) for k in _lib.FcGruWeights.FIELDS}
+        if self.flat_params is None:
+            self.flat_params, self.weights = self._flat(src)
+        for k in _lib.FcGruWeights.FIELDS:
+            self.weights[k].copy_(src[k])
+        self.repack()
+
+    def repack(self):
+        st = self._struct(self.weights)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_fcgru_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def backward(self, logits, probs, labels, loss_type='xentropy'):
+        """Gradients of the loss of gaze_rnn.py:363-408 w.r.t. the 8 variables after forward() on the same
+        inputs; returns {field: gradient view}, the flat buffer is flat_grads."""
+        assert self.save_for_backward, 'create the engine with save_for_backward=True'
+        assert labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous()
+        if self.flat_grads is None:
+            self.flat_grads, self.grads = self._flat(self.weights)
+        st = self._struct(self.grads)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_fcgru_backward(self._h, _ptr(logits), _ptr(probs), _ptr(labels), ctypes.byref(st),
+                                                   {'xentropy': 0, 'l2': 1}[loss_type], _stream_ptr(self.device)))
+        return self.grads
+
+    def adam_step(self, step, lr, max_grad_norm=10.0):
+        return adam_clip_step_multi([self], step, lr, max_grad_norm)
 
     def forward(self, c3d_input, want_probs=True):
         x = c3d_input

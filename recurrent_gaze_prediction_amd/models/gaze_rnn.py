@@ -88,7 +88,8 @@ class GazePredictionGRU(ModelBase):
         if net is None:
             net = {}
         engine = FcGruEngine(model.batch_size, model.n_lstm_steps, (model.gazemap_height, model.gazemap_width),
-                             dtype=getattr(model.config, 'compute_dtype', 'f32'), device=model.session.device)
+                             dtype=getattr(model.config, 'compute_dtype', 'f32'), device=model.session.device,
+                             save_for_backward=getattr(model.config, 'trainable', True))
         model.variables = synthetic.fcgru_params(getattr(model.config, 'init_seed', 0), model.gazemap_height,
                                                  model.gazemap_width)
         engine.set_weights(model.variables)
@@ -96,6 +97,9 @@ class GazePredictionGRU(ModelBase):
         return engine
 
     def state_dict(self):
+        w = getattr(self.engine, 'weights', None)          # trained values live in the engine's master buffer
+        if isinstance(w, dict) and all(k in w for k in self.variables):
+            self.variables = {k: w[k].detach().cpu().numpy().copy() for k in self.variables}
         return {k: np.array(v, copy=True) for k, v in self.variables.items()}
 
     def load_state_dict(self, state):

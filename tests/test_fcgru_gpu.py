@@ -48,3 +48,49 @@ def test_gaze_rnn_model_class_runs_config2(gpu, tmp_path):
     pt = {k: torch.tensor(v) for k, v in model.variables.items()}
     ref = torch.softmax(torch_ref.fcgru_forward(torch.tensor(c3d.reshape(2, 16, 1024, 7, 7)), pt, 7, 7).reshape(2, 16, -1), -1)
     assert rel_err(ret['pred_gazemap_list'][:32].reshape(2, 16, 49), ref.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize('dtype,loss_type', [('f32', 'xentropy'), ('f32', 'l2'), ('bf16', 'xentropy')])
+def test_fcgru_backward_matches_autograd(gpu, dtype, loss_type):
+    """rgp_fcgru_backward: gradients of the reference loss w.r.t. all 8 variables vs float64 autograd."""
+    from recurrent_gaze_prediction_amd.engine import FcGruEngine
+    B, T, GH = 3, 4, 7
+    p = syn.fcgru_params(141, GH, GH)
+    p['gates_bias'] = p['gates_bias'] + np.linspace(-0.3, 0.3, p['gates_bias'].size).astype(np.float32)
+    x = syn.c3d_features(142, B, T)
+    rs = np.random.RandomState(143)
+    gt = rs.rand(B, T, GH, GH).astype(np.float32)
+    gt /= gt.sum(axis=(2, 3), keepdims=True)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    logits_ref = torch_ref.fcgru_forward(torch.tensor(x, dtype=torch.float64), pt, GH, GH)
+    torch_ref.gaze_loss(logits_ref, torch.tensor(gt, dtype=torch.float64), loss_type).backward()
+    eng = FcGruEngine(B, T, (GH, GH), dtype=dtype, device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    logits, probs = eng.forward(torch.tensor(x, device=gpu))
+    grads = eng.backward(logits, probs, torch.tensor(gt, device=gpu), loss_type)
+    tol = 5e-4 if dtype == 'f32' else 5e-2
+    errs = {k: rel_err(grads[k].cpu().numpy(), pt[k].grad.numpy()) for k in p}
+    assert all(np.abs(pt[k].grad.numpy()).max() > 0 for k in p)
+    assert max(errs.values()) < tol, errs
+
+
+def test_config2_training_steps_through_the_model_api(gpu, tmp_path):
+    """GazePredictionGRU.single_step(train_mode=True): fc-GRU training (config 2), loss falls on a fixed batch."""
+    from recurrent_gaze_prediction_amd.models.base import Session
+    from recurrent_gaze_prediction_amd.models.gaze_rnn import GazePredictionGRU, GRUModelConfig
+    cfg = GRUModelConfig()
+    cfg.batch_size, cfg.n_lstm_steps, cfg.compute_dtype, cfg.train_dir = 2, 4, 'bf16', str(tmp_path)
+    cfg.initial_learning_rate = 1e-3
+    ds = type('DS', (), {})()
+    ds.train = ds.valid = syn.SyntheticDataSet(8, 4, seed=9)
+    model = GazePredictionGRU(Session(gpu), ds, cfg)
+    before = model.state_dict()
+    model.single_step(train_mode=False, dataset=syn.SyntheticDataSet(8, 4, seed=9))
+    loss0 = model.loss
+    np.random.seed(1)
+    for i in range(5):
+        assert model.single_step(train_mode=True) == i + 1
+    model.single_step(train_mode=False, dataset=syn.SyntheticDataSet(8, 4, seed=9))
+    assert np.isfinite(model.loss) and model.loss < loss0, (loss0, model.loss)
+    after = model.state_dict()
+    assert not np.array_equal(after['gates_kernel'], before['gates_kernel'])
