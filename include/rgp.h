@@ -204,6 +204,13 @@ int rgp_shallownet_set_weights(rgp_shallownet_t* plan, const rgp_shallownet_weig
 int rgp_shallownet_forward(rgp_shallownet_t* plan, const float* frames, int n_frames, float* saliency,
                            float* saliency7, rgp_stream_t stream);
 
+/* Training (FramewiseShallowNet trains every variable, gaze_framewise_shallownet.py:43-57): with a plan created
+ * by rgp_shallownet_create_ex(save_for_backward = 1), rgp_shallownet_backward takes d loss / d saliency
+ * [n_frames,49,49] fp32 for the frames of the last forward and overwrites grads (arrays shaped like the weights). */
+int rgp_shallownet_create_ex(rgp_shallownet_t** plan, int max_frames, int image_hw, int dtype, int save_for_backward);
+int rgp_shallownet_backward(rgp_shallownet_t* plan, int n_frames, const float* d_saliency, const rgp_shallownet_weights* grads,
+                            rgp_stream_t stream);
+
 /* ------------------------------------------------------------------ two-level cascade (config 5) */
 typedef struct rgp_cascade rgp_cascade_t;
 

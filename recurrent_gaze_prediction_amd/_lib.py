@@ -83,6 +83,8 @@ SIGNATURES = {
     'rgp_fcgru_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rgp_fcgru_create_ex': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
     'rgp_fcgru_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(FcGruWeights), c_int, c_void_p]),
+    'rgp_shallownet_create_ex': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    'rgp_shallownet_backward': (c_int, [c_void_p, c_int, c_void_p, ctypes.POINTER(ShallowNetWeights), c_void_p]),
     'rgp_shallownet_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
     'rgp_shallownet_destroy': (c_int, [c_void_p]),
     'rgp_shallownet_workspace_bytes': (c_size_t, [c_void_p]),

@@ -10,7 +10,8 @@
 // the two overlapping 3x3/2 pools are a streaming kernel.
 #include <algorithm>
 
-#include "rgp_host.h"
+#include "train_kernels.hip.h"
+#include "wgrad_launch.h"
 
 using namespace rgp;
 
@@ -23,6 +24,16 @@ struct rgp_shallownet {
   char* ws = nullptr;
   bool weights_set = false;
   const float *b_conv1 = nullptr, *b_conv2 = nullptr, *b_conv3 = nullptr;
+  // ---- training ----
+  bool save = false;
+  int last_n = 0;
+  size_t amax1 = 0, mask1 = 0, mask2 = 0;         // conv1 pool arg-max [n][p1*p1][32]; maxout masks [n][2401]
+  ConvDesc b_fc2, b_fc1, b_c3, b_c2;               // input-gradient GEMMs / "full" correlations with the rotated filters
+  size_t dz2 = 0, dz1 = 0;                         // T [n+1][kFcN2]
+  size_t dmo1 = 0, dpool3 = 0, dpool2 = 0, dpool1 = 0;   // fp32 [n][K2], [n][Kf], [n][p2*p2*64], [n][p1*p1*32]
+  size_t dy3 = 0, dy2 = 0;                         // T [n][(c+4)^2][C]: gradient w.r.t. the conv outputs, halo 2
+  size_t dy1 = 0;                                  // T [128 zeros][n][c1*c1][32]
+  size_t dw1 = 0;                                  // fp32 conv1 filter gradient in its packed K order
 };
 
 namespace {
@@ -52,6 +63,13 @@ int set_weights_impl(rgp_shallownet* g, const rgp_shallownet_weights* w, hipStre
   interleave_kernel<<<(2401 + 255) / 256, 256, 0, s>>>(w->fc2_b, (float*)(ws + g->b2i), 2401);
   RGP_HIP(hipGetLastError());
   g->b_conv1 = w->conv1_b; g->b_conv2 = w->conv2_b; g->b_conv3 = w->conv3_b;
+  if (g->save) {
+    for (ConvDesc* d : {&g->b_fc2, &g->b_fc1, &g->b_c3, &g->b_c2}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
+    RGP_TRY(pack_filter<T>(g->b_fc2, w->fc2_w, ws, 2401, 0, s));
+    RGP_TRY(pack_filter<T>(g->b_fc1, w->fc1_w, ws, g->nflat, 0, s));
+    RGP_TRY(pack_filter<T>(g->b_c3, w->conv3_w, ws, 64, 0, s));
+    RGP_TRY(pack_filter<T>(g->b_c2, w->conv2_w, ws, 32, 0, s));
+  }
   g->weights_set = true;
   return RGP_OK;
 }
@@ -72,12 +90,14 @@ int forward_impl(rgp_shallownet* g, const float* frames, int n, float* sal, floa
   char* ws = g->ws;
   constexpr int G32 = sizeof(T) == 2 ? 2 : 1;     // 32-element taps: two per 128-byte chunk in bf16
   const long long npix = (long long)n * g->IH * g->IH;
+  g->last_n = n;
   frame_prep_kernel<T><<<(int)std::min<long long>((npix + 255) / 256, 8192), 256, 0, s>>>(frames, (T*)(ws + g->frames4), npix);
   RGP_HIP(hipGetLastError());
   {
     IgemmParams p = make_params(g->conv1, ws + g->frames4, ws, n);
     EpiParams e = make_epi(g->conv1, ws + g->pool1, ws);
     e.bias = g->b_conv1;
+    if (g->save) e.argmax = (unsigned char*)(ws + g->amax1);
     RGP_TRY((launch_igemm<T, G32, 4, EpiStore<T, true, true>>(p, e, s)));
   }
   {
@@ -98,12 +118,14 @@ int forward_impl(rgp_shallownet* g, const float* frames, int n, float* sal, floa
     IgemmParams p = make_params(g->fc1, ws + g->pool3, ws, n);
     EpiParams e = make_epi(g->fc1, ws + g->mo1, ws);
     e.bias = (const float*)(ws + g->b1i);
+    if (g->save) e.argmax = (unsigned char*)(ws + g->mask1);
     RGP_TRY((launch_igemm<T, 1, 1, EpiReluMaxout<T>>(p, e, s)));
   }
   {
     IgemmParams p = make_params(g->fc2, ws + g->mo1, ws, n);
     EpiParams e = make_epi(g->fc2, sal, ws);
     e.bias = (const float*)(ws + g->b2i);
+    if (g->save) e.argmax = (unsigned char*)(ws + g->mask2);
     RGP_TRY((launch_igemm<T, 1, 1, EpiReluMaxout<float>>(p, e, s)));
   }
   if (sal7) {
@@ -123,16 +145,271 @@ void conv_valid_desc(ConvDesc& d, int H_in, int k, int Cin, int Cout, int out_h,
   d.s_tap = (long long)Cin * Cout; d.s_c = Cout; d.s_n = 1;     // HWIO
 }
 
+// ---------------------------------------------------------------- backward (FramewiseShallowNet trains all
+// variables, gaze_framewise_shallownet.py:43-57; everywhere else the ShallowNet has learning rate 0)
+
+// tf.nn.max_pool(3x3 / 2, SAME) + ReLU differentiated: the gradient of a pooled output goes to the first
+// maximum of its window; windows overlap, so each input position gathers from the (up to 4) windows that cover it.
+// x: the conv output after ReLU, dense [n][H][H][C]; dyp: fp32, image stride ld_img, element (oy*OH+ox)*C + c;
+// out: gradient w.r.t. the conv pre-activation in a halo-padded image [n][H+2h][H+2h][C] (h = halo).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_same_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dyp,
+                                                               long long ld_img, T* __restrict__ out, int n, int H, int C, int k,
+                                                               int st, int OH, int pad, int halo) {
+  const long long total = (long long)n * H * H * C;
+  const int Hp = H + 2 * halo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int xx = (int)((i / C) % H);
+    const int yy = (int)((i / ((long long)C * H)) % H);
+    const long long img = i / ((long long)C * H * H);
+    const T* xi = x + img * H * H * C;
+    const float v = Elem<T>::from(xi[((long long)yy * H + xx) * C + c]);
+    float acc = 0.f;
+    if (v > 0.f) {
+      const int oy0 = max(0, (yy + pad - k + 1 + st - 1) / st), oy1 = min(OH - 1, (yy + pad) / st);
+      const int ox0 = max(0, (xx + pad - k + 1 + st - 1) / st), ox1 = min(OH - 1, (xx + pad) / st);
+      for (int oy = oy0; oy <= oy1; ++oy)
+        for (int ox = ox0; ox <= ox1; ++ox) {
+          // first maximum of window (oy, ox) in (wy, wx) scan order
+          float best = -INFINITY;
+          int by = -1, bx = -1;
+          for (int wy = 0; wy < k; ++wy) {
+            const int y2 = oy * st - pad + wy;
+            if (y2 < 0 || y2 >= H) continue;
+            for (int wx = 0; wx < k; ++wx) {
+              const int x2 = ox * st - pad + wx;
+              if (x2 < 0 || x2 >= H) continue;
+              const float w = Elem<T>::from(xi[((long long)y2 * H + x2) * C + c]);
+              if (w > best) { best = w; by = y2; bx = x2; }
+            }
+          }
+          if (by == yy && bx == xx) acc += dyp[img * ld_img + ((long long)oy * OH + ox) * C + c];
+        }
+    }
+    out[((img * Hp + yy + halo) * Hp + xx + halo) * C + c] = Elem<T>::to(acc);
+  }
+}
+
+// conv1's fused 2x2 / 2 pool: route through the arg-max the forward epilogue recorded, gate by pool1 > 0;
+// writes all four window members of dy1 (dense [n][c1][c1][32], behind 128 leading zeros).
+template <typename T>
+__global__ __launch_bounds__(256) void unpool2x2_kernel(const float* __restrict__ dyp, const unsigned char* __restrict__ amax,
+                                                        const T* __restrict__ pooled, T* __restrict__ dy, int n, int PH, int C) {
+  const long long total = (long long)n * PH * PH * C;
+  const int H = 2 * PH;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int xo = (int)((i / C) % PH);
+    const int yo = (int)((i / ((long long)C * PH)) % PH);
+    const long long img = i / ((long long)C * PH * PH);
+    const float g = Elem<T>::from(pooled[i]) > 0.f ? dyp[i] : 0.f;
+    const int code = amax[i];
+    for (int q = 0; q < 4; ++q)
+      dy[((img * H + 2 * yo + (q >> 1)) * H + 2 * xo + (q & 1)) * C + c] = Elem<T>::to(q == code ? g : 0.f);
+  }
+}
+
+// bias gradient of a conv: out[c] = sum over images and positions of a [n][rows_y][rows_x][C] window of a
+// (possibly padded) image; one block per channel
+template <typename T>
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const T* __restrict__ base, int n, long long img_stride, int H, int row_stride,
+                                                             int C, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  const long long total = (long long)n * H * H;
+  float a = 0.f;
+  for (long long i = threadIdx.x; i < total; i += 256) {
+    const int xx = (int)(i % H);
+    const int yy = (int)((i / H) % H);
+    const long long img = i / ((long long)H * H);
+    a += Elem<T>::from(base[img * img_stride + (long long)yy * row_stride + (long long)xx * C + c]);
+  }
+  a = block_reduce(a, sh, false);
+  if (threadIdx.x == 0) out[c] = a;
+}
+
+// conv1 filter gradient: packed K order (ky tap: 8 px x 4 ch) -> HWIO [5,5,3,32]
+__global__ void conv1_unpack_grad_kernel(const float* __restrict__ dw1, float* __restrict__ grad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 5 * 5 * 3 * 32) return;
+  const int n = i % 32, c = (i / 32) % 3, kx = (i / 96) % 5, ky = i / 480;
+  grad[i] = dw1[(long long)(ky * 32 + kx * 4 + c) * 32 + n];
+}
+
+bool bwd_plan(rgp_shallownet* g, Arena& a) {
+  const int dtype = g->dtype, es = esize(dtype);
+  const size_t n = g->N;
+  bool ok = true;
+  // "full" correlation of the halo-2 padded output gradient with the 180-degree rotated, in/out-swapped 3x3 filter
+  auto dgrad3 = [&](ConvDesc& d, int out_h, int in_h, int Cout, int Cin) {
+    const int Wp = out_h + 4;
+    d.Mw = in_h * in_h; d.N = Cin;
+    d.in_img_stride = (long long)Wp * Wp * Cout; d.out_img_stride = (long long)in_h * in_h * Cin;
+    std::vector<int> tapoff, fidx;
+    for (int y = 0; y < in_h; ++y) for (int x = 0; x < in_h; ++x) { d.in_tab.push_back((y * Wp + x) * Cout); d.out_tab.push_back((y * in_h + x) * Cin); }
+    for (int t = 0; t < 9; ++t) { tapoff.push_back(((t / 3) * Wp + t % 3) * Cout); fidx.push_back(8 - t); }
+    ok &= build_k_schedule(d, tapoff, fidx, Cout, dtype);
+    d.s_tap = (long long)Cin * Cout; d.s_n = Cout; d.s_c = 1;          // HWIO [3,3,Cin,Cout]: row = ci, K column = co
+  };
+  dgrad3(g->b_c3, g->c3, g->p2, 32, 64);
+  dgrad3(g->b_c2, g->c2, g->p1, 64, 32);
+  auto fcT = [&](ConvDesc& d, int N, long long out_ld) {
+    d.Mw = 1; d.N = N; d.in_img_stride = kFcN2; d.out_img_stride = out_ld; d.in_tab = {0}; d.out_tab = {0};
+    ok &= build_k_schedule(d, {0}, {0}, kFcN2, dtype);
+    d.cin_src = 4802; d.s_tap = 0; d.s_n = 4802; d.s_c = 1;
+  };
+  fcT(g->b_fc2, 2401, g->K2);
+  fcT(g->b_fc1, g->nflat, g->Kf);
+  if (!ok) return false;
+  for (ConvDesc* d : {&g->b_fc2, &g->b_fc1, &g->b_c3, &g->b_c2}) d->reserve(a, dtype);
+  g->amax1 = a.take(n * g->p1 * g->p1 * 32);
+  g->mask1 = a.take(n * 2401);
+  g->mask2 = a.take(n * 2401);
+  g->dz2 = a.take((n + 1) * kFcN2 * es + 1024);
+  g->dz1 = a.take((n + 1) * kFcN2 * es + 1024);
+  g->dmo1 = a.take(n * g->K2 * 4);
+  g->dpool3 = a.take(n * g->Kf * 4);
+  g->dpool2 = a.take(n * g->p2 * g->p2 * 64 * 4);
+  g->dpool1 = a.take(n * g->p1 * g->p1 * 32 * 4);
+  g->dy3 = a.take(n * (g->c3 + 4) * (g->c3 + 4) * 32 * es + 4096);
+  g->dy2 = a.take(n * (g->c2 + 4) * (g->c2 + 4) * 64 * es + 4096);
+  g->dy1 = a.take((128 + n * g->c1 * g->c1 * 32) * es + 4096);
+  g->dw1 = a.take((size_t)g->conv1.nk * bke(dtype) * 32 * 4);
+  return true;
+}
+
+template <typename T>
+int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallownet_weights* gr, hipStream_t s) {
+  char* ws = g->ws;
+  constexpr int BKE = Elem<T>::BKE;
+  constexpr int G32 = sizeof(T) == 2 ? 2 : 1;
+  auto Tp = [&](size_t off) { return (T*)(ws + off); };
+  auto Fp = [&](size_t off) { return (float*)(ws + off); };
+  auto nblk = [](long long x) { return (int)std::min<long long>((x + 255) / 256, 8192); };
+  WgradParams wp;
+  auto fc_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, size_t dz, float* dW, int k_valid) -> int {
+    RGP_HIP(hipMemsetAsync(dW, 0, (size_t)k_valid * 4802 * 4, s));
+    memset(&wp, 0, sizeof(wp));
+    wp.X = X; wp.dY = ws + dz; wp.dW = dW;
+    wgrad_grid(wp, 1, 1, n);
+    wp.x_sx = ldx; wp.y_sx = kFcN2; wp.y_org = kFcN2;
+    wp.koff = (const int*)(ws + fwd.koff_off);
+    wp.M = n; wp.N = 4802; wp.nk = fwd.nk; wp.ldw = 4802; wp.k_valid = k_valid;
+    return launch_wgrad<T, 1>(wp, s);
+  };
+  // ---- fully connected read-out (saliency_shallownet.py:139-185)
+  maxout_bwd_kernel<T><<<nblk((long long)n * 2401), 256, 0, s>>>(d_sal, 2401, nullptr, 1.0f, (const unsigned char*)(ws + g->mask2),
+                                                                 Tp(g->dz2), (long long)n * 2401);
+  fc_bias_grad_kernel<T><<<(4802 + 255) / 256, 256, 0, s>>>(Tp(g->dz2), n, (float*)gr->fc2_b);
+  RGP_HIP(hipGetLastError());
+  RGP_TRY(fc_wgrad(ws + g->mo1, g->K2, g->fc2, g->dz2, (float*)gr->fc2_w, 2401));
+  {
+    IgemmParams p = make_params(g->b_fc2, Tp(g->dz2) + kFcN2, ws, n);
+    EpiParams e = make_epi(g->b_fc2, Fp(g->dmo1), ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+  }
+  maxout_bwd_kernel<T><<<nblk((long long)n * 2401), 256, 0, s>>>(Fp(g->dmo1), g->K2, nullptr, 1.0f, (const unsigned char*)(ws + g->mask1),
+                                                                 Tp(g->dz1), (long long)n * 2401);
+  fc_bias_grad_kernel<T><<<(4802 + 255) / 256, 256, 0, s>>>(Tp(g->dz1), n, (float*)gr->fc1_b);
+  RGP_HIP(hipGetLastError());
+  RGP_TRY(fc_wgrad(ws + g->pool3, g->Kf, g->fc1, g->dz1, (float*)gr->fc1_w, g->nflat));
+  {
+    IgemmParams p = make_params(g->b_fc1, Tp(g->dz1) + kFcN2, ws, n);
+    EpiParams e = make_epi(g->b_fc1, Fp(g->dpool3), ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+  }
+  // ---- conv3 (3x3 VALID 64 -> 32) behind pool3
+  auto conv_wgrad = [&](const void* X, int in_h, int Cin, const ConvDesc& fwd, size_t dy, int out_h, int Cout, float* dW, int G) -> int {
+    const int Wp = out_h + 4;
+    RGP_HIP(hipMemsetAsync(dW, 0, (size_t)9 * Cin * Cout * 4, s));
+    memset(&wp, 0, sizeof(wp));
+    wp.X = X; wp.dY = ws + dy; wp.dW = dW;
+    wgrad_grid(wp, 1, out_h, out_h);
+    wp.x_sx = Cin; wp.x_sy = in_h * Cin; wp.x_img_stride = (long long)in_h * in_h * Cin;
+    wp.y_sx = Cout; wp.y_sy = Wp * Cout; wp.y_org = (2 * Wp + 2) * Cout; wp.y_img_stride = (long long)Wp * Wp * Cout;
+    wp.koff = (const int*)(ws + fwd.koff_off);
+    wp.M = (long long)n * out_h * out_h; wp.N = Cout; wp.nk = fwd.nk; wp.ldw = Cout; wp.k_valid = 9 * Cin;
+    return G == 1 ? launch_wgrad<T, 1>(wp, s) : launch_wgrad<T, G32>(wp, s);
+  };
+  {
+    const int H = g->c3, OH = g->p3, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
+    maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 32), 256, 0, s>>>(Tp(g->act3), Fp(g->dpool3), g->Kf, Tp(g->dy3), n, H, 32, 3, 2,
+                                                                              OH, pad, 2);
+    conv_bias_grad_kernel<T><<<32, 256, 0, s>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, n, (long long)Wp * Wp * 32, H, Wp * 32, 32,
+                                                (float*)gr->conv3_b);
+    RGP_HIP(hipGetLastError());
+    RGP_TRY(conv_wgrad(ws + g->pool2, g->p2, 64, g->conv3, g->dy3, H, 32, (float*)gr->conv3_w, 1));
+    IgemmParams p = make_params(g->b_c3, Tp(g->dy3), ws, n);
+    EpiParams e = make_epi(g->b_c3, Fp(g->dpool2), ws);
+    RGP_TRY((launch_igemm<T, G32, 1, EpiStore<float, false, false>>(p, e, s)));
+  }
+  // ---- conv2 (3x3 VALID 32 -> 64) behind pool2
+  {
+    const int H = g->c2, OH = g->p2, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
+    maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 64), 256, 0, s>>>(Tp(g->act2), Fp(g->dpool2), (long long)OH * OH * 64, Tp(g->dy2),
+                                                                              n, H, 64, 3, 2, OH, pad, 2);
+    conv_bias_grad_kernel<T><<<64, 256, 0, s>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, n, (long long)Wp * Wp * 64, H, Wp * 64, 64,
+                                                (float*)gr->conv2_b);
+    RGP_HIP(hipGetLastError());
+    RGP_TRY(conv_wgrad(ws + g->pool1, g->p1, 32, g->conv2, g->dy2, H, 64, (float*)gr->conv2_w, G32));
+    IgemmParams p = make_params(g->b_c2, Tp(g->dy2), ws, n);
+    EpiParams e = make_epi(g->b_c2, Fp(g->dpool1), ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+  }
+  // ---- conv1 (5x5 VALID 3 -> 32) with its fused 2x2 pool; no input gradient (the input is the image)
+  {
+    const int H = g->c1, IH = g->IH;
+    T* dy1 = Tp(g->dy1) + 128;
+    unpool2x2_kernel<T><<<nblk((long long)n * g->p1 * g->p1 * 32), 256, 0, s>>>(Fp(g->dpool1), (const unsigned char*)(ws + g->amax1),
+                                                                               Tp(g->pool1), dy1, n, g->p1, 32);
+    conv_bias_grad_kernel<T><<<32, 256, 0, s>>>(dy1, n, (long long)H * H * 32, H, H * 32, 32, (float*)gr->conv1_b);
+    RGP_HIP(hipGetLastError());
+    RGP_HIP(hipMemsetAsync(Fp(g->dw1), 0, (size_t)g->conv1.nk * BKE * 32 * 4, s));
+    memset(&wp, 0, sizeof(wp));
+    wp.X = ws + g->frames4; wp.dY = Tp(g->dy1); wp.dW = Fp(g->dw1);
+    wgrad_grid(wp, 1, H, H);
+    wp.x_sx = 4; wp.x_sy = IH * 4; wp.x_img_stride = (long long)IH * IH * 4;
+    wp.y_sx = 32; wp.y_sy = H * 32; wp.y_org = 128; wp.y_img_stride = (long long)H * H * 32;
+    wp.koff = (const int*)(ws + g->conv1.koff_off);
+    wp.M = (long long)n * H * H; wp.N = 32; wp.nk = g->conv1.nk; wp.ldw = 32; wp.k_valid = g->conv1.nk * BKE;
+    RGP_TRY((launch_wgrad<T, G32>(wp, s)));
+    conv1_unpack_grad_kernel<<<(5 * 5 * 3 * 32 + 255) / 256, 256, 0, s>>>(Fp(g->dw1), (float*)gr->conv1_w);
+    RGP_HIP(hipGetLastError());
+  }
+  return RGP_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
+int rgp_shallownet_backward(rgp_shallownet_t* g, int n_frames, const float* d_saliency, const rgp_shallownet_weights* grads,
+                            rgp_stream_t stream) {
+  RGP_REQUIRE(g && d_saliency && grads, "rgp_shallownet_backward: null argument");
+  if (!g->save) return set_err(RGP_ESTATE, "rgp_shallownet_backward: plan was created without save_for_backward");
+  if (!g->ws || !g->weights_set) return set_err(RGP_ESTATE, "rgp_shallownet_backward: workspace/weights not set");
+  if (n_frames != g->last_n || n_frames <= 0)
+    return set_err(RGP_ESTATE, "rgp_shallownet_backward: n_frames %d != frames of the last forward (%d)", n_frames, g->last_n);
+  const float* const* ptrs = (const float* const*)grads;
+  for (size_t i = 0; i < sizeof(rgp_shallownet_weights) / sizeof(float*); ++i)
+    RGP_REQUIRE(ptrs[i], "rgp_shallownet_backward: gradient pointer %zu is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  return g->dtype == RGP_BF16 ? backward_impl<bf16_t>(g, n_frames, d_saliency, grads, s)
+                              : backward_impl<float>(g, n_frames, d_saliency, grads, s);
+}
+
 int rgp_shallownet_create(rgp_shallownet_t** plan, int max_frames, int image_hw, int dtype) {
+  return rgp_shallownet_create_ex(plan, max_frames, image_hw, dtype, 0);
+}
+
+int rgp_shallownet_create_ex(rgp_shallownet_t** plan, int max_frames, int image_hw, int dtype, int save_for_backward) {
   RGP_REQUIRE(plan && max_frames > 0, "rgp_shallownet_create: bad arguments");
   RGP_REQUIRE(image_hw == 98 || image_hw == 112, "rgp_shallownet_create: image %d (98 or 112)", image_hw);
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_shallownet_create: dtype %d", dtype);
   rgp_shallownet* g = new rgp_shallownet();
   g->N = max_frames; g->IH = image_hw; g->dtype = dtype;
+  g->save = save_for_backward != 0;
   g->c1 = image_hw - 4; g->p1 = g->c1 / 2; g->c2 = g->p1 - 2; g->p2 = (g->c2 + 1) / 2; g->c3 = g->p2 - 2; g->p3 = (g->c3 + 1) / 2;
   g->nflat = g->p3 * g->p3 * 32;
   g->Kf = (int)align_up(g->nflat, 64);
@@ -181,6 +458,7 @@ int rgp_shallownet_create(rgp_shallownet_t** plan, int max_frames, int image_hw,
   g->mo1 = a.take(n * g->K2 * es);
   g->b1i = a.take(4802 * 4 + 64);
   g->b2i = a.take(4802 * 4 + 64);
+  if (g->save && !bwd_plan(g, a)) { delete g; return set_err(RGP_EINVAL, "rgp_shallownet_create: backward K schedule failed"); }
   g->ws_bytes = a.off;
   *plan = g;
   return RGP_OK;
@@ -202,6 +480,7 @@ int rgp_shallownet_bind_workspace(rgp_shallownet_t* g, void* workspace, size_t b
   g->weights_set = false;
   RGP_HIP(hipMemsetAsync(g->ws, 0, g->ws_bytes, s));
   for (ConvDesc* d : {&g->conv1, &g->conv2, &g->conv3, &g->fc1, &g->fc2}) RGP_TRY(upload_desc(*d, g->ws, s));
+  if (g->save) for (ConvDesc* d : {&g->b_fc2, &g->b_fc1, &g->b_c3, &g->b_c2}) RGP_TRY(upload_desc(*d, g->ws, s));
   return RGP_OK;
 }
 

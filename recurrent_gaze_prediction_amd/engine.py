@@ -306,14 +306,16 @@ class FcGruEngine(object):
 class ShallowNetEngine(object):
     """Frame-wise ShallowNet (models/saliency_shallownet.py:74-216, BASELINE config 1)."""
 
-    def __init__(self, max_frames, image_hw=98, dtype='f32', device='cuda:0'):
+    def __init__(self, max_frames, image_hw=98, dtype='f32', device='cuda:0', save_for_backward=False):
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.max_frames, self.image_hw, self.dtype = int(max_frames), int(image_hw), dtype
+        self.save_for_backward = bool(save_for_backward)
+        self.flat_params = self.flat_grads = self.grads = self.adam_m = self.adam_v = None
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.rgp_shallownet_create(ctypes.byref(self._h), self.max_frames, self.image_hw,
-                                                      _lib.DTYPES[dtype]))
+            _lib.check(self.lib.rgp_shallownet_create_ex(ctypes.byref(self._h), self.max_frames, self.image_hw,
+                                                         _lib.DTYPES[dtype], int(self.save_for_backward)))
             nbytes = self.lib.rgp_shallownet_workspace_bytes(self._h)
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_shallownet_bind_workspace(self._h, _ptr(self.workspace), nbytes,
@@ -325,14 +327,50 @@ class ShallowNetEngine(object):
         if h:
             self.lib.rgp_shallownet_destroy(h)
 
-    def set_weights(self, params):
-        w = {k: _as_dev_f32(params[k], self.device) for k in _lib.ShallowNetWeights.FIELDS}
+    def _flat(self, like):
+        sizes = [(k, tuple(like[k].shape)) for k in _lib.ShallowNetWeights.FIELDS]
+        flat = torch.zeros(sum(int(np.prod(s)) for _, s in sizes), dtype=torch.float32, device=self.device)
+        views, off = {}, 0
+        for k, shp in sizes:
+            n = int(np.prod(shp))
+            views[k] = flat[off:off + n].view(shp)
+            off += n
+        return flat, views
+
+    def _struct(self, views):
         st = _lib.ShallowNetWeights()
         for k in _lib.ShallowNetWeights.FIELDS:
-            setattr(st, k, w[k].data_ptr())
-        self.weights = w
+            setattr(st, k, views[k].data_ptr())
+        return st
+
+    def set_weights(self, params):
+        src = {k: _as_dev_f32(params[k], self.device) for k in _lib.ShallowNetWeights.FIELDS}
+        if self.flat_params is None:
+            self.flat_params, self.weights = self._flat(src)
+        for k in _lib.ShallowNetWeights.FIELDS:
+            self.weights[k].copy_(src[k])
+        self.repack()
+
+    def repack(self):
+        st = self._struct(self.weights)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_shallownet_set_weights(self._h, ctypes.byref(st), _stream_ptr(self.device)))
+
+    def backward(self, d_saliency):
+        """d loss / d saliency [n,49,49] fp32 (frames of the last forward) -> {field: gradient view} for all ten
+        variables (FramewiseShallowNet trains them all, gaze_framewise_shallownet.py:43-57)."""
+        assert self.save_for_backward, 'create the engine with save_for_backward=True'
+        d = d_saliency
+        assert d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and tuple(d.shape[1:]) == (49, 49)
+        if self.flat_grads is None:
+            self.flat_grads, self.grads = self._flat(self.weights)
+        st = self._struct(self.grads)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_shallownet_backward(self._h, d.shape[0], _ptr(d), ctypes.byref(st), _stream_ptr(self.device)))
+        return self.grads
+
+    def adam_step(self, step, lr, max_grad_norm=10.0):
+        return adam_clip_step_multi([self], step, lr, max_grad_norm)
 
     def forward(self, frames, want_7x7=False):
         """frames [n,H,W,3] fp32 device tensor -> (saliency [n,49,49], saliency7 [n,7,7] or None)."""

@@ -28,11 +28,35 @@ class _FramewiseEngine(object):
         self.model = model
         hw = getattr(model.config, 'image_hw', CONSTANTS.image_height)
         self.net = ShallowNetEngine(model.batch_size * model.n_lstm_steps, hw,
-                                    dtype=getattr(model.config, 'compute_dtype', 'f32'), device=model.session.device)
+                                    dtype=getattr(model.config, 'compute_dtype', 'f32'), device=model.session.device,
+                                    save_for_backward=getattr(model.config, 'trainable', True))
         self.frames = None
 
     def set_weights(self, params):
         self.net.set_weights(params)
+
+    # ---- training contract of GazePredictionGRU._train_op (backward -> all-reduce of flat_grads -> adam_step)
+    @property
+    def flat_grads(self):
+        return self.net.flat_grads
+
+    @property
+    def weights(self):
+        return self.net.weights
+
+    def backward(self, logits, probs, labels, loss_type='l2'):
+        """l2 loss of gaze_rnn.py:387-389 on the emitted maps; a 7x7 map is the 7x7 average pool of the 49x49 one
+        (gaze_rnn.py:262-269), so its gradient spreads uniformly over each 7x7 cell."""
+        assert loss_type == 'l2', 'FramewiseShallowNet is trained with the l2 loss (gaze_framewise_shallownet.py:43-57)'
+        m = self.model
+        F = m.batch_size * m.n_lstm_steps
+        d = (logits - labels.reshape(logits.shape)) / float(F)
+        if (m.gazemap_height, m.gazemap_width) == (7, 7):
+            d = d.reshape(F, 7, 1, 7, 1).expand(F, 7, 7, 7, 7).reshape(F, 49, 49) / 49.0
+        return self.net.backward(d.reshape(F, 49, 49).contiguous())
+
+    def adam_step(self, step, lr, max_grad_norm=10.0):
+        return self.net.adam_step(step, lr, max_grad_norm)
 
     def forward(self, c3d, want_probs=False):
         m = self.model
