@@ -15,9 +15,9 @@
 //   A frag : lane (row, kgroup) reads LDS voxel hp[row] + tap_shift[tap], 16-B chunk
 //            (kgroup ^ voxel&7)  -- same XOR swizzle as the DMA source permutation.
 //   B tile : packed filter rows n0..n0+BN, K-tile (tap, chunk) at k = tap*Cin + chunk*BKE,
-//            double-buffered LDS-DMA exactly as in igemm_kernel.
-//   K loop : for chunk in Cin/BKE: for tap in 27: one barrier per K-tile; the NEXT chunk's
-//            halo is prefetched one DMA per wave per K-tile into the second halo buffer.
+//            streamed by LDS-DMA through a 3-stage ring, issued two taps ahead.
+//   K loop : for chunk in Cin/BKE: for tap in 27: counted vmcnt + one raw barrier per K-tile; the halo is
+//            reloaded at each chunk switch (a second halo buffer does not fit next to the ring).
 #pragma once
 #include "igemm.hip.h"
 
@@ -33,6 +33,7 @@ struct HaloParams {
   int Cin, N, K;            // K = 27*Cin
   int nchunks;              // Cin / BKE
   int HP8;                  // halo voxels, padded to a multiple of 8
+  int shift_y, shift_z;     // halo-voxel index step of one tap in y (= HX) and z (= HY*HX)
   int n_img;
   int nbx, nby, nbz;        // boxes per image
   int box_in_x, box_in_y, box_in_z;   // element offset of one box step in the input  (elements)
@@ -42,8 +43,8 @@ struct HaloParams {
 template <int BM, int BN>
 struct HaloSmem {
   static constexpr int B_STAGE = BN * 128;
-  static constexpr int B_OFF = 0;                         // 2 filter stages
-  static constexpr int HALO_OFF = 2 * B_STAGE;
+  static constexpr int B_OFF = 0;                         // 3 filter stages (ring)
+  static constexpr int HALO_OFF = 3 * B_STAGE;
   static constexpr int halo_bytes(int hp8) { return hp8 * 128; }
 };
 
@@ -130,23 +131,37 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_halo_kernel(const HaloPara
   const int b_off = (wn * WTN + frow) * 128;
   const int bpc0 = ((0 * 4 + fk) ^ (frow & 7)) * 16, bpc1 = ((1 * 4 + fk) ^ (frow & 7)) * 16;
 
+  // Fragment reads are inline asm with their own lgkmcnt wait: through plain loads the compiler orders every LDS
+  // read after ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the filter ring every tap.
+  static_assert(MI == 4 && NI == 4, "64x64 wave tiles");
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned halo_lds = lds_base + (unsigned)(halo0 - smem);
   auto compute = [&](int hb, int bbuf, int tap) {
-    const char* hbase = halo0 + hb * halo_bytes;
-    const char* bbase = smem + bbuf * B_STAGE + b_off;
-    const int sh = s_tapshift[tap];
-    f32x4 a[2][MI], b[2][NI];
+    const unsigned hbase = halo_lds + hb * halo_bytes;
+    const unsigned bbase = lds_base + bbuf * B_STAGE + b_off;
+    // halo-voxel shift of tap (kz,ky,kx), computed (an LDS table read here would make the compiler drain the DMA ring)
+    const int sh = (tap / 9) * p.shift_z + ((tap / 3) % 3) * p.shift_y + tap % 3;
+    unsigned aa[2][MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int v = hp[i] + sh;
-      const char* row = hbase + v * 128;
-      a[0][i] = *(const f32x4*)(row + (((0 * 4 + fk) ^ (v & 7)) << 4));
-      a[1][i] = *(const f32x4*)(row + (((1 * 4 + fk) ^ (v & 7)) << 4));
+      aa[0][i] = hbase + v * 128 + (((0 * 4 + fk) ^ (v & 7)) << 4);
+      aa[1][i] = hbase + v * 128 + (((1 * 4 + fk) ^ (v & 7)) << 4);
     }
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      b[0][j] = *(const f32x4*)(bbase + j * 16 * 128 + bpc0);
-      b[1][j] = *(const f32x4*)(bbase + j * 16 * 128 + bpc1);
-    }
+    f32x4 a[2][MI], b[2][NI];
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+        "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+        : "=&v"(a[0][0]), "=&v"(a[0][1]), "=&v"(a[0][2]), "=&v"(a[0][3]), "=&v"(a[1][0]), "=&v"(a[1][1]), "=&v"(a[1][2]), "=&v"(a[1][3])
+        : "v"(aa[0][0]), "v"(aa[0][1]), "v"(aa[0][2]), "v"(aa[0][3]), "v"(aa[1][0]), "v"(aa[1][1]), "v"(aa[1][2]), "v"(aa[1][3])
+        : "memory");
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:2048\n\tds_read_b128 %2, %8 offset:4096\n\tds_read_b128 %3, %8 offset:6144\n\t"
+        "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:2048\n\tds_read_b128 %6, %9 offset:4096\n\tds_read_b128 %7, %9 offset:6144\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[0][2]), "=&v"(b[0][3]), "=&v"(b[1][0]), "=&v"(b[1][1]), "=&v"(b[1][2]), "=&v"(b[1][3])
+        : "v"(bbase + bpc0), "v"(bbase + bpc1)
+        : "memory");
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -155,36 +170,44 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_halo_kernel(const HaloPara
         for (int j = 0; j < NI; ++j) Mma<T>::step(acc[i][j], a[s][i], b[s][j]);
   };
 
-  // ---- prologue: halo of chunk 0 and filter K-tile (tap 0, chunk 0) ----
-  for (int i = wave; i < n_hinst; i += NW) halo_dma(0, 0, i);
-  stage_b(0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
+  // ---- K loop: the input halo of one channel chunk is LDS-resident for its 27 taps; the filter K-tiles
+  // stream through a 3-stage ring issued two taps ahead (counted vmcnt, one raw barrier per tap: a wait
+  // for everything in flight would expose the whole L2 latency of the next tile every tap). ----
   const int nk = 27 * p.nchunks;
-  int tap = 0, cc = 0, bbuf = 0;
-  int hnext = wave;          // next halo DMA instruction (of chunk cc+1) this wave issues
+  auto kt_tap = [&](int kt) { return kt % 27; };
+  auto kt_cc = [&](int kt) { return kt / 27; };
+  for (int i = wave; i < n_hinst; i += NW) halo_dma(0, 0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // keeps the ring's vmcnt arithmetic free of halo loads
+  // hp[] came from a global load: re-define the registers here, behind the wait, or the compiler guards their first
+  // use inside the loop with its own vmcnt(0) (the in-order counter then also covers the ring's DMA)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(hp[i]));
+  stage_b(0, 0, 0);
+  if (nk > 1) stage_b(1, kt_tap(1), kt_cc(1));
 #pragma clang loop unroll(disable)
   for (int kt = 0; kt < nk; ++kt) {
-    int tap_n = tap + 1, cc_n = cc;
-    if (tap_n == 27) { tap_n = 0; cc_n = cc + 1; }
-    if (kt + 1 < nk) stage_b(bbuf ^ 1, tap_n, cc_n);
-    if (cc + 1 < p.nchunks && hnext < n_hinst) {     // trickle-prefetch next chunk's halo
-      halo_dma((cc + 1) & 1, cc + 1, hnext);
-      hnext += NW;
+    const int tap = kt_tap(kt), cc = kt_cc(kt);
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // K-tile kt landed for every wave; stage (kt+2)%3 is free
+    asm volatile("" ::: "memory");         // the barrier builtin does not order plain LDS loads: keep compute() below it
+    if (kt + 2 < nk) stage_b((kt + 2) % 3, kt_tap(kt + 2), kt_cc(kt + 2));
+    compute(0, kt % 3, tap);
+    if (tap == 26 && cc + 1 < p.nchunks) {
+      // chunk switch: every wave is done with the resident halo, reload it (exposed once per chunk)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int i = wave; i < n_hinst; i += NW) halo_dma(0, cc + 1, i);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    compute(cc & (halo_bufs - 1), bbuf, tap);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    bbuf ^= 1;
-    if (tap_n == 0) hnext = wave;
-    tap = tap_n;
-    cc = cc_n;
   }
+  __syncthreads();
 
   // ---- epilogue (same slab scheme as igemm_kernel; rows = box voxels) ----
   constexpr int LDS_LD = BN + 4;
-  float* stg = (float*)halo0;
+  float* stg = (float*)smem;      // the filter ring is free now (WTM x (BN+4) floats fit in its 3 stages)
+  static_assert(WTM * (BN + 4) * 4 <= 3 * B_STAGE, "epilogue slab fits in the filter ring");
   constexpr int CG = BN / 8;
   constexpr int ITEMS = (WTM / P) * CG;
 #pragma unroll 1
@@ -203,15 +226,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3d_halo_kernel(const HaloPara
       const int g = it / CG, cg = it - g * CG;
       float v[8];
       const float* src = stg + (g * P) * LDS_LD + cg * 8;
-      f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-#pragma unroll
-      for (int q = 1; q < P; ++q) {
-        const f32x4 w0 = *(const f32x4*)(src + q * LDS_LD), w1 = *(const f32x4*)(src + q * LDS_LD + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], w0[i]); v1[i] = fmaxf(v1[i], w1[i]); }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+      pool_window<P>(src, LDS_LD, v);
       Epi::apply(e, p.N, img, (slab * WTM) / P + g, n0 + cg * 8, v);
     }
     __syncthreads();

@@ -72,6 +72,7 @@ int run_halo(rgp_c3d* c, int i, int n, hipStream_t s) {
   p.Cin = kLayers[i].cin; p.N = d.N; p.K = d.K;
   p.nchunks = kLayers[i].cin / Elem<T>::BKE;
   p.HP8 = h.HP8; p.n_img = n;
+  p.shift_y = h.BX + 2; p.shift_z = (h.BY + 2) * (h.BX + 2);
   p.nbx = h.nbx; p.nby = h.nby; p.nbz = h.nbz;
   p.box_in_x = h.box_in[0]; p.box_in_y = h.box_in[1]; p.box_in_z = h.box_in[2];
   p.box_out_x = h.box_out[0]; p.box_out_y = h.box_out[1]; p.box_out_z = h.box_out[2];
@@ -79,8 +80,8 @@ int run_halo(rgp_c3d* c, int i, int n, hipStream_t s) {
   e.out_tab = (const int*)(c->ws + h.out_tab_off);
   e.bias = c->bias[i];
   auto kern = conv3d_halo_kernel<T, BM, BN, WM, WN, P, EpiStore<T, true, true>>;
-  const int bufs = p.nchunks > 1 ? 2 : 1;
-  const int smem = 2 * BN * 128 + bufs * h.HP8 * 128 + h.HP8 * 4 + 27 * 4;
+  const int bufs = 1;       // the 3-stage filter ring leaves room for one resident halo chunk
+  const int smem = 3 * BN * 128 + bufs * h.HP8 * 128 + h.HP8 * 4 + 27 * 4;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -100,9 +101,9 @@ int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   // the halo kernel needs (2 filter stages + 1 or 2 halo buffers) <= 160 KiB of LDS;
   // otherwise (fp32 conv2a: two 75 KiB halo chunks) the im2col tile loop runs instead
   const int bn_ = i == 1 ? 128 : 256;
-  const int bufs_ = kLayers[i].cin / Elem<T>::BKE > 1 ? 2 : 1;
-  const bool fits = 2 * bn_ * 128 + bufs_ * c->halo[i].HP8 * 128 + c->halo[i].HP8 * 4 + 108 <= 160 * 1024;
-  if (use_halo && c->halo[i].used && fits) {
+  const bool fits = 3 * bn_ * 128 + c->halo[i].HP8 * 128 + c->halo[i].HP8 * 4 + 108 <= 160 * 1024;
+  // (training plans record the pooling arg-max, which only the im2col epilogues do)
+  if (use_halo && c->halo[i].used && fits && !c->save) {
     if (i == 1) return run_halo<T, 256, 128, 4, 2, 8>(c, i, n, s);
     if (i == 2) return run_halo<T, 128, 256, 2, 4, 1>(c, i, n, s);
     if (i == 3) return run_halo<T, 128, 256, 2, 4, 8>(c, i, n, s);
