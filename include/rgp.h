@@ -144,6 +144,16 @@ int rgp_adam_clip_step_ext(float* params, const float* grads, float* m, float* v
                            int n_partials, int step, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                            float* grad_norm_out, rgp_stream_t stream);
 
+/* Graph-replayable optimizer step: the learning-rate schedule (gaze_rnn.py:436-444: lr0 * decay^floor(step /
+ * decay_steps)) and Adam's bias correction are evaluated ON THE DEVICE from a device-resident step counter, so a
+ * whole training step captured in a HIP graph replays correctly.  rgp_lr_schedule_step writes lr_t and advances
+ * the counter (once per training step); rgp_adam_clip_step_dev is rgp_adam_clip_step_ext reading lr_t. */
+int rgp_lr_schedule_step(int* step_dev, float lr0, float decay, int decay_steps, float beta1, float beta2, float* lr_t_dev,
+                         rgp_stream_t stream);
+int rgp_adam_clip_step_dev(float* params, const float* grads, float* m, float* v, long long n, const float* partials,
+                           int n_partials, const float* lr_t_dev, float beta1, float beta2, float eps, float max_grad_norm,
+                           float* grad_norm_out, rgp_stream_t stream);
+
 /* Stage timing (HIP events recorded on the caller's stream around each stage launch
  * group; costs two hipEventRecord per stage).  Stages: 0 proj (incl. transpose),
  * 1 xconv, 2 convgru sequence, 3 head (transposed convs), 4 softmax.

@@ -125,6 +125,10 @@ SIGNATURES = {
     'rgp_adam_clip_step_ext': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_int,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        c_void_p, c_void_p]),
+    'rgp_lr_schedule_step': (c_int, [c_void_p, ctypes.c_float, ctypes.c_float, c_int, ctypes.c_float, ctypes.c_float,
+                                     c_void_p, c_void_p]),
+    'rgp_adam_clip_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_void_p,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
     'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
     'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),

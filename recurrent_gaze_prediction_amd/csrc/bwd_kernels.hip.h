@@ -310,7 +310,8 @@ static __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* __restrict__ sq_partial, int n_partial, float clip,
                                                         float lr_t, float b1, float b2, float eps,
-                                                        float* __restrict__ norm_out) {
+                                                        float* __restrict__ norm_out, const float* __restrict__ lr_t_dev) {
+  if (lr_t_dev) lr_t = *lr_t_dev;       // step size computed on the device (graph-replayable training step)
   float sq = 0.f;
   for (int i = 0; i < n_partial; ++i) sq += sq_partial[i];     // same order in every thread
   const float norm = sqrtf(sq);
@@ -323,6 +324,20 @@ static __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict
     m[i] = mi;
     v[i] = vi;
     p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// Learning-rate schedule + Adam bias correction evaluated on the device, so that a captured training step
+// (HIP graph) can be replayed: lr_t = lr0 * decay^floor(step/decay_steps) * sqrt(1-b2^t)/(1-b1^t), t = step+1
+// (gaze_rnn.py:436-444, TF AdamOptimizer); then step += 1.
+static __global__ void lr_schedule_kernel(int* __restrict__ step, float lr0, float decay, int decay_steps, float b1, float b2,
+                                          float* __restrict__ lr_t) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int s = *step;
+    const double t = (double)s + 1.0;
+    const double lr = (double)lr0 * pow((double)decay, (double)(s / decay_steps));
+    *lr_t = (float)(lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    *step = s + 1;
   }
 }
 

@@ -405,7 +405,7 @@ int rgp_adam_clip_step(float* params, const float* grads, float* m, float* v, lo
   const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   adam_clip_kernel<<<blocks, 256, 0, s>>>(params, grads, m, v, n, workspace, SQ_BLOCKS, max_grad_norm, lr_t, beta1, beta2,
-                                          eps, grad_norm_out);
+                                          eps, grad_norm_out, nullptr);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
@@ -426,7 +426,26 @@ int rgp_adam_clip_step_ext(float* params, const float* grads, float* m, float* v
   const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   adam_clip_kernel<<<blocks, 256, 0, s>>>(params, grads, m, v, n, partials, n_partials, max_grad_norm, lr_t, beta1, beta2, eps,
-                                          grad_norm_out);
+                                          grad_norm_out, nullptr);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+int rgp_lr_schedule_step(int* step_dev, float lr0, float decay, int decay_steps, float beta1, float beta2, float* lr_t_dev,
+                         rgp_stream_t stream) {
+  RGP_REQUIRE(step_dev && lr_t_dev && decay_steps > 0, "rgp_lr_schedule_step: bad arguments");
+  lr_schedule_kernel<<<1, 64, 0, (hipStream_t)stream>>>(step_dev, lr0, decay, decay_steps, beta1, beta2, lr_t_dev);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+int rgp_adam_clip_step_dev(float* params, const float* grads, float* m, float* v, long long n, const float* partials,
+                           int n_partials, const float* lr_t_dev, float beta1, float beta2, float eps, float max_grad_norm,
+                           float* grad_norm_out, rgp_stream_t stream) {
+  RGP_REQUIRE(params && grads && m && v && partials && lr_t_dev && n > 0 && n_partials > 0, "rgp_adam_clip_step_dev: bad arguments");
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+  adam_clip_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, grads, m, v, n, partials, n_partials, max_grad_norm, 0.f, beta1,
+                                                            beta2, eps, grad_norm_out, lr_t_dev);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
