@@ -7,6 +7,7 @@
 #include "rgp_c3d_plan.h"
 #include "conv1a.hip.h"
 #include "conv3d_halo.hip.h"
+#include "conv3d_halo_stagger.hip.h"
 
 using namespace rgp;
 
@@ -93,6 +94,42 @@ int run_halo(rgp_c3d* c, int i, int n, hipStream_t s) {
   return RGP_OK;
 }
 
+// halo-resident + staggered two-group schedule (conv3d_halo_stagger.hip.h)
+template <typename T, int BM, int BN, int WM, int WN, int NST, int P>
+int run_halo_stagger(rgp_c3d* c, int i, int n, hipStream_t s) {
+  const HaloDesc& h = c->halo[i];
+  const ConvDesc& d = c->L[i];
+  HaloParams p;
+  p.A = c->ws + c->act_off[i];
+  p.W = c->ws + d.w_off;
+  p.halo_goff = (const int*)(c->ws + h.goff_off);
+  p.row_hp = (const int*)(c->ws + h.row_hp_off);
+  p.tap_shift = (const int*)(c->ws + h.tap_shift_off);
+  p.in_img_stride = d.in_img_stride;
+  p.Cin = kLayers[i].cin; p.N = d.N; p.K = d.K;
+  p.nchunks = kLayers[i].cin / Elem<T>::BKE;
+  p.HP8 = h.HP8; p.n_img = n;
+  p.shift_y = h.BX + 2; p.shift_z = (h.BY + 2) * (h.BX + 2);
+  p.nbx = h.nbx; p.nby = h.nby; p.nbz = h.nbz;
+  p.box_in_x = h.box_in[0]; p.box_in_y = h.box_in[1]; p.box_in_z = h.box_in[2];
+  p.box_out_x = h.box_out[0]; p.box_out_y = h.box_out[1]; p.box_out_z = h.box_out[2];
+  EpiParams e = make_epi(d, c->ws + c->act_off[i + 1], c->ws);
+  e.out_tab = (const int*)(c->ws + h.out_tab_off);
+  e.bias = c->bias[i];
+  auto kern = conv3d_halo_stagger_kernel<T, BM, BN, WM, WN, NST, P, EpiStore<T, true, true>>;
+  const int smem = NST * BN * 128 + h.HP8 * 128;
+  if (h.HP8 > 640 || smem > 160 * 1024) return set_err(RGP_EINVAL, "halo-stagger kernel: LDS budget (layer %d)", i);
+  static bool attr_done = false;
+  if (!attr_done) {
+    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  const int grid = n * h.nbx * h.nby * h.nbz * (d.N / BN);
+  kern<<<grid, 512, smem, s>>>(p, e);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 template <typename T>
 int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   // LDS-halo direct kernel: correct but not faster than the staggered tile loop yet;
@@ -103,7 +140,12 @@ int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   const int bn_ = i == 1 ? 128 : 256;
   const bool fits = 3 * bn_ * 128 + c->halo[i].HP8 * 128 + c->halo[i].HP8 * 4 + 108 <= 160 * 1024;
   // (training plans record the pooling arg-max, which only the im2col epilogues do)
-  if (use_halo && c->halo[i].used && fits && !c->save) {
+  if (use_halo == 2 && c->halo[i].used && !c->save) {
+    if (i == 1) return run_halo_stagger<T, 256, 128, 4, 2, 4, 8>(c, i, n, s);
+    if (i == 2) return run_halo_stagger<T, 128, 256, 2, 4, 3, 1>(c, i, n, s);
+    if (i == 3) return run_halo_stagger<T, 128, 256, 2, 4, 3, 8>(c, i, n, s);
+  }
+  if (use_halo == 1 && c->halo[i].used && fits && !c->save) {
     if (i == 1) return run_halo<T, 256, 128, 4, 2, 8>(c, i, n, s);
     if (i == 2) return run_halo<T, 128, 256, 2, 4, 1>(c, i, n, s);
     if (i == 3) return run_halo<T, 128, 256, 2, 4, 8>(c, i, n, s);
