@@ -64,7 +64,7 @@ def test_c3d_chunking_equals_single_pass(gpu, c3d_case):
     assert torch.equal(fa, fb)
 
 
-@pytest.mark.parametrize('env', [{'RGP_TILE': '0'}, {'RGP_HALO': '1'}, {'RGP_TILE': '1'}])
+@pytest.mark.parametrize('env', [{'RGP_TILE': '0'}, {'RGP_HALO': '1'}, {'RGP_HALO': '2'}, {'RGP_TILE': '1'}])
 def test_alternative_conv_kernels_stay_correct(gpu, env):
     """The 128x128 tile loop, the 256x128 simple loop and the LDS-halo direct kernel are selected by
     environment knobs read once per process, so each runs in a child process: 8 windows (enough rows
