@@ -145,7 +145,73 @@ def metrics_case(name, seed=40, n=12):
     print(name, {k: float(np.mean(out[k])) for k in ('sim', 'cc', 'AUC_Judd', 'AUC_Borji')})
 
 
+def _t64(p):
+    return {k: _t64(v) if isinstance(v, dict) else torch.tensor(v, dtype=torch.float64) for k, v in p.items()}
+
+
+def cascade_case(name, B, T, seed):
+    """gaze_grcn_cascade.py (config 5): maps, intermediates' checksums, l2 loss and the gradient norm of every
+    trainable variable (ShallowNet frozen), float64 torch oracle."""
+    p = syn.cascade_params(seed)
+    rs = np.random.RandomState(seed + 7)
+    frames = rs.rand(B, T, 98, 98, 3).astype(np.float32)
+    c3d = syn.c3d_features(seed + 8, B, T)
+    gt, _ = syn.gaze_maps(seed + 9, B, T)
+    gt = (gt / gt.max()).astype(np.float32)
+    tp = _t64(p)
+    for k, v in tp.items():
+        if k != 'ShallowNet':
+            v.requires_grad_(True)
+    maps, mid = torch_ref.cascade_forward(torch.tensor(frames, dtype=torch.float64), torch.tensor(c3d, dtype=torch.float64), tp,
+                                          want_all=True)
+    loss = torch_ref.gaze_loss(maps, torch.tensor(gt, dtype=torch.float64), 'l2')
+    loss.backward()
+    out = dict(config=np.array([B, T, seed]), maps=maps.detach().numpy().astype(np.float32), loss=np.float64(loss.item()))
+    for k, v in mid.items():
+        out['abs_sum_' + k] = np.float64(v.detach().abs().sum().item())
+    for k, v in tp.items():
+        if k != 'ShallowNet':
+            out['gnorm_' + k.replace('/', '.')] = np.float64(v.grad.norm().item())
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, 'loss', out['loss'], 'maps max', float(maps.max()))
+
+
+def fcgru_case(name, B, T, GH, seed):
+    p = syn.fcgru_params(seed, GH, GH)
+    x = syn.c3d_features(seed + 1, B, T)
+    rs = np.random.RandomState(seed + 2)
+    gt = rs.rand(B, T, GH, GH).astype(np.float32)
+    gt /= gt.sum(axis=(2, 3), keepdims=True)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    logits = torch_ref.fcgru_forward(torch.tensor(x, dtype=torch.float64), tp, GH, GH)
+    loss = torch_ref.gaze_loss(logits, torch.tensor(gt, dtype=torch.float64))
+    loss.backward()
+    out = dict(config=np.array([B, T, GH, seed]), logits=logits.detach().numpy().astype(np.float32), loss=np.float64(loss.item()))
+    for k, v in tp.items():
+        out['gnorm_' + k] = np.float64(v.grad.norm().item())
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, 'loss', out['loss'])
+
+
+def frontend_case(name, seed):
+    """VIDEO_DATA layer oracle (oracle/c3d_frontend.py): 240x320 frames -> one 16x112x112x3 window; a strided
+    sample of the output (the full window is regenerated from the seed in the tests)."""
+    from oracle import c3d_frontend as ofe
+    rs = np.random.RandomState(seed)
+    frames = rs.randint(0, 256, size=(18, 240, 320, 3)).astype(np.uint8)
+    mean = (rs.rand(3, 16, 128, 171) * 120).astype(np.float32)
+    v = ofe.video_data_layer(frames, [1], mean)
+    np.savez_compressed(os.path.join(HERE, name), config=np.array([seed]), sample=v[0, ::3, ::7, ::5].astype(np.float32),
+                        checksum=np.float64(np.abs(v.astype(np.float64)).sum()))
+    print(name, 'checksum', float(np.abs(v.astype(np.float64)).sum()))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'new':         # fixtures added after the first set
+        cascade_case('cascade_small.npz', 1, 2, 131)
+        fcgru_case('fcgru_small.npz', 2, 3, 7, 141)
+        frontend_case('frontend_window.npz', 151)
+        sys.exit(0)
     grcn_case('grcn_small.npz', 2, 3, 64, 64, 101, use_numpy=True)
     grcn_case('grcn_refdims.npz', 1, 2, 512, 128, 111, use_numpy=False)
     grads_case('grcn_grads_small.npz', 2, 3, 64, 64, 101)

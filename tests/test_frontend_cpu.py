@@ -210,3 +210,15 @@ def test_video_data_layer_crop_offsets_and_mean():
     assert v.shape == (2, 16, 112, 112, 3)
     assert v[1, 3, 5, 7, 2] == np.float32(frames[23, 13, 36, 2]) - mean[2, 3, 13, 36]
     assert np.array_equal(ofe.video_data_layer(frames, [16])[0, 0], frames[16, 8:120, 29:141].astype(np.float32))
+
+
+def test_video_data_layer_oracle_reproduces_golden():
+    """tests/golden/frontend_window.npz pins the VIDEO_DATA restatement (240x320 frames, window starting at frame 1)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'frontend_window.npz'))
+    rs = np.random.RandomState(int(g['config'][0]))
+    frames = rs.randint(0, 256, size=(18, 240, 320, 3)).astype(np.uint8)
+    mean = (rs.rand(3, 16, 128, 171) * 120).astype(np.float32)
+    v = ofe.video_data_layer(frames, [1], mean)
+    assert np.array_equal(v[0, ::3, ::7, ::5], g['sample'])
+    assert abs(float(np.abs(v.astype(np.float64)).sum()) - float(g['checksum'])) < 1e-9 * float(g['checksum'])

@@ -231,3 +231,20 @@ def test_cascade_oracle_closed_forms():
     f1 = np.maximum(f1[:2401], f1[2401:])
     f2 = np.maximum(f1 @ p['LastProjection/fc2_w'].astype(np.float64) + p['LastProjection/fc2_b'], 0)
     assert np.allclose(maps0, np.broadcast_to(np.maximum(f2[:2401], f2[2401:]).reshape(49, 49), maps0.shape), atol=1e-12)
+
+
+def test_oracle_reproduces_cascade_and_fcgru_golden():
+    """Later fixtures (make_golden.py new): the float64 oracle reproduces its committed outputs."""
+    g = np.load(os.path.join(GOLD, 'fcgru_small.npz'))
+    B, T, GH, seed = [int(v) for v in g['config']]
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in syn.fcgru_params(seed, GH, GH).items()}
+    logits = torch_ref.fcgru_forward(torch.tensor(syn.c3d_features(seed + 1, B, T), dtype=torch.float64), p, GH, GH).numpy()
+    assert np.abs(logits - g['logits']).max() < 1e-5 * np.abs(g['logits']).max()
+    g = np.load(os.path.join(GOLD, 'cascade_small.npz'))
+    B, T, seed = [int(v) for v in g['config']]
+    tt = lambda d: {k: tt(v) if isinstance(v, dict) else torch.tensor(v, dtype=torch.float64) for k, v in d.items()}
+    rs = np.random.RandomState(seed + 7)
+    frames = rs.rand(B, T, 98, 98, 3).astype(np.float32)
+    maps = torch_ref.cascade_forward(torch.tensor(frames, dtype=torch.float64),
+                                     torch.tensor(syn.c3d_features(seed + 8, B, T), dtype=torch.float64), tt(syn.cascade_params(seed))).numpy()
+    assert np.abs(maps - g['maps']).max() < 1e-5 * np.abs(g['maps']).max()
