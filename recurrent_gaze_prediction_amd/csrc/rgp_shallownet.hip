@@ -210,23 +210,32 @@ __global__ __launch_bounds__(256) void unpool2x2_kernel(const float* __restrict_
   }
 }
 
-// bias gradient of a conv: out[c] = sum over images and positions of a [n][rows_y][rows_x][C] window of a
-// (possibly padded) image; one block per channel
+// bias gradient of a conv: out[c] += sum over images and positions of an H x H window of a (possibly padded)
+// channels-last image.  Thread = (row lane, 8-channel group): 16-byte reads, per-block LDS reduction, one atomic
+// per channel and block (out is zeroed by the caller).
 template <typename T>
-__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const T* __restrict__ base, int n, long long img_stride, int H, int row_stride,
-                                                             int C, float* __restrict__ out) {
-  __shared__ float sh[4];
-  const int c = blockIdx.x;
-  const long long total = (long long)n * H * H;
-  float a = 0.f;
-  for (long long i = threadIdx.x; i < total; i += 256) {
-    const int xx = (int)(i % H);
-    const int yy = (int)((i / H) % H);
-    const long long img = i / ((long long)H * H);
-    a += Elem<T>::from(base[img * img_stride + (long long)yy * row_stride + (long long)xx * C + c]);
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const T* __restrict__ base, long long img_stride, int H, int row_stride,
+                                                             int C, long long rows_total, float* __restrict__ out) {
+  __shared__ float red[256 * 8];
+  const int CG = C / 8;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RL = 256 / CG;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long r = (long long)blockIdx.x * RL + rl; r < rows_total; r += (long long)gridDim.x * RL) {
+    const int xx = (int)(r % H);
+    const int yy = (int)((r / H) % H);
+    const long long img = r / ((long long)H * H);
+    const T* q = base + img * img_stride + (long long)yy * row_stride + (long long)xx * C + cg * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bsum[k] += Elem<T>::from(q[k]);
   }
-  a = block_reduce(a, sh, false);
-  if (threadIdx.x == 0) out[c] = a;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rl * C + cg * 8 + k] = bsum[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < RL; ++r) a += red[r * C + c];
+    if (a != 0.f) atomicAdd(out + c, a);
+  }
 }
 
 // conv1 filter gradient: packed K order (ky tap: 8 px x 4 ch) -> HWIO [5,5,3,32]
@@ -336,8 +345,9 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
     const int H = g->c3, OH = g->p3, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
     maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 32), 256, 0, s>>>(Tp(g->act3), Fp(g->dpool3), g->Kf, Tp(g->dy3), n, H, 32, 3, 2,
                                                                               OH, pad, 2);
-    conv_bias_grad_kernel<T><<<32, 256, 0, s>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, n, (long long)Wp * Wp * 32, H, Wp * 32, 32,
-                                                (float*)gr->conv3_b);
+    RGP_HIP(hipMemsetAsync((void*)gr->conv3_b, 0, 32 * 4, s));
+    conv_bias_grad_kernel<T><<<nblk((long long)n * H * H * 2), 256, 0, s>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, (long long)Wp * Wp * 32, H, Wp * 32,
+                                                                           32, (long long)n * H * H, (float*)gr->conv3_b);
     RGP_HIP(hipGetLastError());
     RGP_TRY(conv_wgrad(ws + g->pool2, g->p2, 64, g->conv3, g->dy3, H, 32, (float*)gr->conv3_w, 1));
     IgemmParams p = make_params(g->b_c3, Tp(g->dy3), ws, n);
@@ -349,8 +359,9 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
     const int H = g->c2, OH = g->p2, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
     maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 64), 256, 0, s>>>(Tp(g->act2), Fp(g->dpool2), (long long)OH * OH * 64, Tp(g->dy2),
                                                                               n, H, 64, 3, 2, OH, pad, 2);
-    conv_bias_grad_kernel<T><<<64, 256, 0, s>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, n, (long long)Wp * Wp * 64, H, Wp * 64, 64,
-                                                (float*)gr->conv2_b);
+    RGP_HIP(hipMemsetAsync((void*)gr->conv2_b, 0, 64 * 4, s));
+    conv_bias_grad_kernel<T><<<nblk((long long)n * H * H * 4), 256, 0, s>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, (long long)Wp * Wp * 64, H, Wp * 64,
+                                                                           64, (long long)n * H * H, (float*)gr->conv2_b);
     RGP_HIP(hipGetLastError());
     RGP_TRY(conv_wgrad(ws + g->pool1, g->p1, 32, g->conv2, g->dy2, H, 64, (float*)gr->conv2_w, G32));
     IgemmParams p = make_params(g->b_c2, Tp(g->dy2), ws, n);
@@ -363,7 +374,9 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
     T* dy1 = Tp(g->dy1) + 128;
     unpool2x2_kernel<T><<<nblk((long long)n * g->p1 * g->p1 * 32), 256, 0, s>>>(Fp(g->dpool1), (const unsigned char*)(ws + g->amax1),
                                                                                Tp(g->pool1), dy1, n, g->p1, 32);
-    conv_bias_grad_kernel<T><<<32, 256, 0, s>>>(dy1, n, (long long)H * H * 32, H, H * 32, 32, (float*)gr->conv1_b);
+    RGP_HIP(hipMemsetAsync((void*)gr->conv1_b, 0, 32 * 4, s));
+    conv_bias_grad_kernel<T><<<nblk((long long)n * H * H * 2), 256, 0, s>>>(dy1, (long long)H * H * 32, H, H * 32, 32, (long long)n * H * H,
+                                                                           (float*)gr->conv1_b);
     RGP_HIP(hipGetLastError());
     RGP_HIP(hipMemsetAsync(Fp(g->dw1), 0, (size_t)g->conv1.nk * BKE * 32 * 4, s));
     memset(&wp, 0, sizeof(wp));
