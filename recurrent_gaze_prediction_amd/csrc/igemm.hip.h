@@ -316,7 +316,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8 + NW - 1) / NW;
-  constexpr int BKE = Elem<T>::BKE;
   constexpr int ESZ = sizeof(T);
   constexpr int TILE_BYTES = IgemmSmem<BM, BN>::TILE_BYTES;
   static_assert((BM / 8) % NW == 0, "A groups must divide over waves");
@@ -380,7 +379,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     const int r = (wave * A_PER_WAVE + j) * 8 + lrow;
     a_src[j] = (const char*)p.A + s_rowin[r] * ESZ + (lchunk % (8 / G)) * 16;
   }
-  const int asub = lchunk / (8 / G);
   const char* b_src[B_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < B_PER_WAVE; ++j) {

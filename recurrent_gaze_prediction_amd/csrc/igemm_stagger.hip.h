@@ -37,11 +37,10 @@ struct StaggerSmem {
 
 template <typename T, int P, class Epi, int ABLATE = 0>
 __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p, const EpiParams e) {
-  constexpr int BM = StaggerSmem::BM, BN = StaggerSmem::BN, WM = 4, WN = 2;
+  constexpr int BM = StaggerSmem::BM, BN = StaggerSmem::BN, WM = 4;
   constexpr int NW = 8, NT = 512;
   constexpr int WTM = 64, WTN = 64, MI = 4, NI = 4;
   constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8) / NW;   // 4, 2
-  constexpr int DMA_PER_TILE = A_PER_WAVE + B_PER_WAVE;                  // 6 per wave
   constexpr int ESZ = sizeof(T);
   constexpr int STAGE = StaggerSmem::STAGE_BYTES;
 

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
   constexpr int BKE = Elem<T>::BKE;               // filter rows per K-chunk (64 bf16, 32 fp32)
   constexpr int CI = BKE / 16;                    // 16-row tiles per chunk
   constexpr int NYL = ESZ == 2 ? 1 : 2;           // dY DMA instructions per thread and step
-  constexpr int YROWB = 128 * ESZ;                // bytes per dY tile row
   constexpr int PER_STEP = 2 + NYL;               // DMA instructions per thread and step
   using S = WgradSmem<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,6 +76,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave >> 1, wn = wave & 1;
   const int n_kt = (p.nk + 3) / 4;
+  // (Dealing whole row ranges to one XCD so that its L2 serves all their K-tiles was measured: conv4b -10 %, but
+  // conv2a / conv3a / conv3b +15...25 % -- the plain order, K-tiles of a row range spread over the XCDs, stays.)
   const int kt = blockIdx.x % n_kt, nt = blockIdx.x / n_kt;
   const int n0 = nt * 128;
   const long long m_begin = (long long)blockIdx.y * p.steps_per_split * 32;
