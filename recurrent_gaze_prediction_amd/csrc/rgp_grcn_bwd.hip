@@ -66,7 +66,12 @@ int wgrad_gemm(const rgp_grcn* g, const T* AT, int rows, const T* BT, int N, lon
   e.out_tab = (const int*)(g->ws + b->o_zero1);
   e.out_img_stride = N;
   const int tiles = ((rows + 127) / 128) * ((N + 127) / 128);
-  int ksplit = std::max(1, std::min(1024 / std::max(tiles, 1), p.nk / 4));
+  // split-K: every split adds rows x N fp32 atomics (the 1024-block rule used before spent 40 % of config 4's
+  // training step in these GEMMs).  Measured optimum on MI355X: ~128 blocks in total for short reductions
+  // (B*T*49 = 13.7 k rows: 7.3 -> 5.1 ms per step), ~256 for long ones (50 k rows: 9.9 -> 7.7 ms); RGP_WG_BLOCKS overrides.
+  static const int target_env = getenv("RGP_WG_BLOCKS") ? atoi(getenv("RGP_WG_BLOCKS")) : 0;
+  const int target = target_env > 0 ? target_env : (p.nk > 400 ? 256 : 128);
+  int ksplit = std::max(1, std::min(target / std::max(tiles, 1), p.nk / 8));
   ksplit = std::max(1, std::min(ksplit, 64));
   return launch_igemm<T, 1, 1, EpiAtomicAddF32>(p, e, s, ksplit);
 }

@@ -20,8 +20,9 @@ int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if (p.M <= 0 || p.nk <= 0 || p.N <= 0) return set_err(RGP_EINVAL, "wgrad: empty problem");
   const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + 127) / 128;
   const long long total_steps = (p.M + 31) / 32;
-  // row ranges (splits): enough for ~1000 blocks, at least 8
-  long long splits = std::max<long long>(8, 1024 / (n_kt * n_nt));
+  // row ranges (splits): enough for ~1000 blocks (RGP_WGK_BLOCKS overrides), at least 8
+  static const int target = getenv("RGP_WGK_BLOCKS") ? atoi(getenv("RGP_WGK_BLOCKS")) : 1024;
+  long long splits = std::max<long long>(8, target / (n_kt * n_nt));
   splits = std::min(splits, total_steps);
   WgradParams q = p;
   q.steps_per_split = (int)((total_steps + splits - 1) / splits);
