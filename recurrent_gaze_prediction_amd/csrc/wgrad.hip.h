@@ -40,6 +40,7 @@ struct WgradParams {
   int Mw, N, nk, ldw;
   int k_valid;             // rows of dW that exist (<= nk*BKE); the rest of the last chunk is channel padding
   int steps_per_split;     // 32-row steps per blockIdx.y
+  int ablate;              // dev diagnostics (RGP_WG_ABLATE): 1 = no reads/MFMA, 2 = no in-loop DMA, 4 = no barrier; results are garbage
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -236,9 +237,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
   for (int s = 0; s < nsteps; ++s) {
     if (PER_STEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
-    issue((s + 2) % 3);
-    compute(s % 3);
+    if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
+    if (!(p.ablate & 2)) issue((s + 2) % 3);
+    if (!(p.ablate & 1)) compute(s % 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

@@ -25,6 +25,8 @@ int launch_wgrad(const WgradParams& p, hipStream_t s) {
   long long splits = std::max<long long>(8, target / (n_kt * n_nt));
   splits = std::min(splits, total_steps);
   WgradParams q = p;
+  static const int ablate = getenv("RGP_WG_ABLATE") ? atoi(getenv("RGP_WG_ABLATE")) : 0;
+  q.ablate = ablate;
   q.steps_per_split = (int)((total_steps + splits - 1) / splits);
   splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
   kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
