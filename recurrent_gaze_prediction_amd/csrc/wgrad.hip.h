@@ -6,16 +6,18 @@
 // i.e. (im2col)^T x dY with the REDUCTION over the output rows m.  Both operands are stored with the
 // reduction index strided in memory (activations are channels-last), the opposite of what an MFMA
 // fragment wants, so:
-//  * row tiles [32 rows][128 B] of X (per K-chunk) and [32 rows][128 cols] of dY are staged by LDS-DMA
-//    exactly as they lie in HBM (full 128/256-B lines, no transposing gather),
+//  * row tiles [32 rows][128 B] of X (per K-chunk) and [32 rows][BN cols] of dY are staged by LDS-DMA
+//    exactly as they lie in HBM (full 128/256/512-B lines, no transposing gather),
 //  * bf16 fragments are read with ds_read_b64_tr_b16, the gfx950 transposing LDS read: a 16-lane group
 //    fetches a 4-row x 16-column block and each lane receives one column = 4 consecutive reduction
 //    indices of its channel; two reads make the 8-deep k-group of v_mfma_f32_16x16x32_bf16,
 //  * 32-byte segments are XOR-swizzled per row (on the DMA source side, the LDS image is lane-linear)
 //    so the 8 rows a 32-lane half touches fall in 8 different bank groups,
 //  * fp32 uses v_mfma_f32_16x16x4_f32 whose fragments are single dwords: plain ds_read_b32.
-// Block tile: 4 K-chunks (4 x 64 bf16 / 4 x 32 fp32 filter rows) x 128 output channels, 8 waves as
-// 4 (chunk) x 2 (64 columns); the reduction is split over blockIdx.y and combined with fp32 atomics.
+// Block tile: 4 K-chunks (4 x 64 bf16 / 4 x 32 fp32 filter rows) x BN = 32*WNT output channels, 8 waves as
+// 4 (chunk) x 2 (16*WNT columns); the reduction is split over blockIdx.y and combined with fp32 atomics.
+// WNT = 4 (BN 128, two blocks per CU) or 8 (BN 256, one block per CU: a third fewer LDS-DMA bytes and a quarter
+// fewer fragment reads per FLOP -- the kernel is LDS-DMA-ingest bound).
 // 3-stage DMA ring, one raw barrier per 32-row step, counted vmcnt.
 #pragma once
 #include "igemm.hip.h"
@@ -47,9 +49,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T> struct WgradSmem {
+template <typename T, int WNT> struct WgradSmem {
+  static constexpr int BN = 32 * WNT;
   static constexpr int XB = 4 * 32 * 128;                    // 4 chunks x 32 rows x 128 B
-  static constexpr int YB = 32 * 128 * (int)sizeof(T);       // 32 rows x 128 columns
+  static constexpr int YB = 32 * BN * (int)sizeof(T);        // 32 rows x BN columns
   static constexpr int STAGE = XB + YB;
   static constexpr int BYTES = 3 * STAGE;
 };
@@ -62,14 +65,18 @@ template <typename T> __device__ __forceinline__ int wg_swz_y(int r) {
   return sizeof(T) == 2 ? 2 * ((r & 3) | (((r >> 3) & 1) << 2)) : 0;
 }
 
-template <typename T, int G>
-__global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
+template <typename T, int G, int WNT>
+__global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad_kernel(const WgradParams p) {
   constexpr int ESZ = sizeof(T);
   constexpr int BKE = Elem<T>::BKE;               // filter rows per K-chunk (64 bf16, 32 fp32)
   constexpr int CI = BKE / 16;                    // 16-row tiles per chunk
-  constexpr int NYL = ESZ == 2 ? 1 : 2;           // dY DMA instructions per thread and step
+  constexpr int BN = 32 * WNT;                    // output channels per block
+  constexpr int YROW = BN * ESZ;                  // bytes per dY tile row
+  constexpr int CPR = YROW / 16;                  // 16-byte chunks per dY tile row
+  constexpr int NYL = (32 * CPR) / 512;           // dY DMA instructions per thread and step
   constexpr int PER_STEP = 2 + NYL;               // DMA instructions per thread and step
-  using S = WgradSmem<T>;
+  using S = WgradSmem<T, WNT>;
+  static_assert(WNT == 4 || WNT == 8, "wave tile 64x64 or 64x128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
   // (Dealing whole row ranges to one XCD so that its L2 serves all their K-tiles was measured: conv4b -10 %, but
   // conv2a / conv3a / conv3b +15...25 % -- the plain order, K-tiles of a row range spread over the XCDs, stays.)
   const int kt = blockIdx.x % n_kt, nt = blockIdx.x / n_kt;
-  const int n0 = nt * 128;
+  const int n0 = nt * BN;
   const long long m_begin = (long long)blockIdx.y * p.steps_per_split * 32;
   long long m_end = m_begin + (long long)p.steps_per_split * 32;
   if (m_end > p.M) m_end = p.M;
@@ -99,12 +106,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     const int sub = ce / elems_per_sub, off = ce - sub * elems_per_sub;
     xsrc_k[u] = (const char*)p.X + ((long long)p.koff[kc * G + sub] + off) * ESZ;
   }
+  // dY: lane-load q = tid + 512 u covers tile row q / CPR, physical chunk q % CPR (the LDS image is lane-linear)
   int yr[NYL], yc[NYL];
 #pragma unroll
   for (int u = 0; u < NYL; ++u) {
-    yr[u] = ESZ == 2 ? (tid >> 4) : ((tid >> 5) + 16 * u);
-    const int phys = ESZ == 2 ? (tid & 15) : (tid & 31);
-    yc[u] = phys ^ wg_swz_y<T>(yr[u]);
+    const int q = tid + 512 * u;
+    yr[u] = q / CPR;
+    yc[u] = (q % CPR) ^ wg_swz_y<T>(yr[u]);
   }
   // running (image, z, y, x) of each owned row; a step advances every row by 32
   struct RowPos { int img, z, y, x; };
@@ -151,19 +159,18 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
       const char* src = (const char*)p.dY;
       if (ok) src += ((long long)r.img * p.y_img_stride + p.y_org + r.z * p.y_sz + r.y * p.y_sy + r.x * p.y_sx + n0) * ESZ + yc[u] * 16;
       else src += (yc[u] & 7) * 16;                                        // zeros (halo)
-      const int ldsoff = ESZ == 2 ? wave * 1024 : (16 * u + 2 * wave) * 512;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(yb + ldsoff), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(yb + wave * 1024 + u * 8192), 16, 0, 0);
       advance(ypos[u]);
     }
     ++n_issued;
   };
 
-  f32x4 acc[CI][4];
+  f32x4 acc[CI][WNT];
 #pragma unroll
   for (int i = 0; i < CI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fcol = lane & 15, g = lane >> 4;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -177,11 +184,11 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
       // The transposing reads are written as inline asm: issued through the builtin, the compiler orders
       // every LDS read after ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which drains the two tiles in
       // flight and serialises the ring.  The asm carries its own lgkmcnt wait; A's registers are consumed
-      // only by MFMAs that also need B's, so one wait at the end of the second block covers both.
+      // only by MFMAs that also need B's, so one wait at the end of the last block covers them all.
       static_assert(CI == 4, "bf16 chunk = 4 x 16 filter rows");
       const unsigned xa = lds_base + (unsigned)(xb - smem) + row * 128 + pp * 8;
-      const unsigned ya = lds_base + (unsigned)(yb - smem) + row * 256 + pp * 8;
-      i32x2 al[4], ah[4], bl[4], bh[4];
+      const unsigned ya = lds_base + (unsigned)(yb - smem) + row * YROW + pp * 8;
+      i32x2 al[4], ah[4], bl[WNT], bh[WNT];
       asm volatile(
           "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
           "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:512\n\t"
@@ -190,41 +197,67 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
           : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&v"(al[3]), "=&v"(ah[3])
           : "v"(xa + ((0 ^ sx) * 32)), "v"(xa + ((1 ^ sx) * 32)), "v"(xa + ((2 ^ sx) * 32)), "v"(xa + ((3 ^ sx) * 32))
           : "memory");
-      asm volatile(
-          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
-          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
-          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
-          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1024\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(bl[0]), "=&v"(bh[0]), "=&v"(bl[1]), "=&v"(bh[1]), "=&v"(bl[2]), "=&v"(bh[2]), "=&v"(bl[3]), "=&v"(bh[3])
-          : "v"(ya + (((wn * 4 + 0) ^ sy) * 32)), "v"(ya + (((wn * 4 + 1) ^ sy) * 32)), "v"(ya + (((wn * 4 + 2) ^ sy) * 32)),
-            "v"(ya + (((wn * 4 + 3) ^ sy) * 32))
-          : "memory");
-      f32x4 a[CI], b[4];
+      // rows row+4 of the dY tile are 4*YROW bytes further: 1024 (BN 128) or 2048 (BN 256)
+#pragma unroll
+      for (int jb = 0; jb < WNT; jb += 4) {
+        if constexpr (WNT == 4) {
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1024"
+              : "=&v"(bl[jb]), "=&v"(bh[jb]), "=&v"(bl[jb + 1]), "=&v"(bh[jb + 1]), "=&v"(bl[jb + 2]), "=&v"(bh[jb + 2]), "=&v"(bl[jb + 3]),
+                "=&v"(bh[jb + 3])
+              : "v"(ya + (((wn * WNT + jb + 0) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 1) ^ sy) * 32)),
+                "v"(ya + (((wn * WNT + jb + 2) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 3) ^ sy) * 32))
+              : "memory");
+        } else {
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
+              "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
+              "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
+              "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:2048"
+              : "=&v"(bl[jb]), "=&v"(bh[jb]), "=&v"(bl[jb + 1]), "=&v"(bh[jb + 1]), "=&v"(bl[jb + 2]), "=&v"(bh[jb + 2]), "=&v"(bl[jb + 3]),
+                "=&v"(bh[jb + 3])
+              : "v"(ya + (((wn * WNT + jb + 0) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 1) ^ sy) * 32)),
+                "v"(ya + (((wn * WNT + jb + 2) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 3) ^ sy) * 32))
+              : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // the fragment registers are valid only behind the wait: re-define them there
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(al[i]), "+v"(ah[i]));
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
+      f32x4 a[CI], b[WNT];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const i32x4 va = {al[i][0], al[i][1], ah[i][0], ah[i][1]};
-        const i32x4 vb = {bl[i][0], bl[i][1], bh[i][0], bh[i][1]};
         a[i] = __builtin_bit_cast(f32x4, va);
-        b[i] = __builtin_bit_cast(f32x4, vb);
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const i32x4 vb = {bl[j][0], bl[j][1], bh[j][0], bh[j][1]};
+        b[j] = __builtin_bit_cast(f32x4, vb);
       }
 #pragma unroll
       for (int i = 0; i < CI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
+        for (int j = 0; j < WNT; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
     } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int row = 4 * s + g;
-        float a[CI], b[4];
+        float a[CI], b[WNT];
 #pragma unroll
         for (int i = 0; i < CI; ++i) a[i] = *(const float*)(xb + row * 128 + (i * 16 + fcol) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *(const float*)(yb + row * 512 + ((wn * 4 + j) * 16 + fcol) * 4);
+        for (int j = 0; j < WNT; ++j) b[j] = *(const float*)(yb + row * YROW + ((wn * WNT + j) * 16 + fcol) * 4);
 #pragma unroll
         for (int i = 0; i < CI; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -235,8 +268,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
   issue(1);
 #pragma clang loop unroll(disable)
   for (int s = 0; s < nsteps; ++s) {
-    if (PER_STEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
     if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
     if (!(p.ablate & 2)) issue((s + 2) % 3);
     if (!(p.ablate & 1)) compute(s % 3);
@@ -249,8 +281,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < CI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + (wn * 4 + j) * 16 + fcol;
+      for (int j = 0; j < WNT; ++j) {
+        const int n = n0 + (wn * WNT + j) * 16 + fcol;
         if (n < p.N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

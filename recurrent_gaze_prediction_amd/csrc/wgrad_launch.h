@@ -1,5 +1,5 @@
-// Host-side launch of wgrad_kernel: tiles of 4 K-chunks x 128 output channels, the row reduction split
-// over blockIdx.y so that about a thousand blocks are in flight.
+// Host-side launch of wgrad_kernel: tiles of 4 K-chunks x 128 (WNT 4) or 256 (WNT 8) output channels, the row
+// reduction split over blockIdx.y so that about a thousand blocks are in flight.
 #pragma once
 #include <algorithm>
 
@@ -8,17 +8,18 @@
 
 namespace rgp {
 
-template <typename T, int G>
-int launch_wgrad(const WgradParams& p, hipStream_t s) {
-  auto kern = wgrad_kernel<T, G>;
-  constexpr int smem = WgradSmem<T>::BYTES;
+template <typename T, int G, int WNT>
+int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
+  auto kern = wgrad_kernel<T, G, WNT>;
+  constexpr int smem = WgradSmem<T, WNT>::BYTES;
+  constexpr int BN = 32 * WNT;
   static bool attr_done = false;
   if (!attr_done) {
     RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
   }
   if (p.M <= 0 || p.nk <= 0 || p.N <= 0) return set_err(RGP_EINVAL, "wgrad: empty problem");
-  const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + 127) / 128;
+  const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + BN - 1) / BN;
   const long long total_steps = (p.M + 31) / 32;
   // row ranges (splits): enough for ~1000 blocks (RGP_WGK_BLOCKS overrides), at least 8
   static const int target = getenv("RGP_WGK_BLOCKS") ? atoi(getenv("RGP_WGK_BLOCKS")) : 1024;
@@ -32,6 +33,19 @@ int launch_wgrad(const WgradParams& p, hipStream_t s) {
   kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
+}
+
+// The 256-wide tile (one block per CU, a third fewer LDS-DMA bytes per FLOP) pays only for few tiles with a long
+// reduction -- conv3a / conv3b: -3 % -- and loses 5...15 % where the 128-wide kernel already has hundreds of
+// tiles (conv4*, conv5*: two co-resident blocks hide each other's barriers).  RGP_WG_WIDE=0 / 2 forces never / always.
+template <typename T, int G>
+int launch_wgrad(const WgradParams& p, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    static const int wide = getenv("RGP_WG_WIDE") ? atoi(getenv("RGP_WG_WIDE")) : 1;
+    const int narrow_tiles = ((p.nk + 3) / 4) * ((p.N + 127) / 128);
+    if (wide && p.N % 256 == 0 && (wide == 2 || narrow_tiles <= 64)) return launch_wgrad_t<T, G, 8>(p, s);
+  }
+  return launch_wgrad_t<T, G, 4>(p, s);
 }
 
 // geometry helpers: rows of one image are the positions (z, y, x) of a D x H x W grid
