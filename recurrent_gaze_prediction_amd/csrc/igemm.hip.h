@@ -127,9 +127,18 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const fl
   }
 }
 
+// Element offset of output row (img, ml) inside e.out.  The staggered kernel resolves it once per row in its
+// prologue (a table lookup per item in the epilogue is a dependent global load per slab) and hands it to apply_at().
+__device__ __forceinline__ long long epi_out_base(const EpiParams& e, int img, int ml) {
+  return (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml];
+}
+
 // out = [relu](acc + bias) stored as TO.
 template <typename TO, bool BIAS, bool RELU> struct EpiStore {
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    apply_at(e, N, img, ml, epi_out_base(e, img, ml), n0, v);
+  }
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int, int, long long base, int n0, float* v) {
     const int nvalid = N - n0;
     if (nvalid <= 0) return;
 #pragma unroll
@@ -137,18 +146,27 @@ template <typename TO, bool BIAS, bool RELU> struct EpiStore {
       if (BIAS) v[i] += (i < nvalid) ? e.bias[n0 + i] : 0.f;
       if (RELU) v[i] = fmaxf(v[i], 0.f);
     }
-    TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
-    store8<TO>(dst, v, nvalid);
+    store8<TO>((TO*)e.out + base + n0, v, nvalid);
   }
+};
+
+// A kernel that has the bias of its 8 columns in registers adds it itself and calls NoBias::apply_at.
+template <class E> struct EpiBiasSplit { static constexpr bool value = false; using NoBias = E; };
+template <typename TO, bool RELU> struct EpiBiasSplit<EpiStore<TO, true, RELU>> {
+  static constexpr bool value = true;
+  using NoBias = EpiStore<TO, false, RELU>;
 };
 
 // dgrad through a ReLU: out = acc where the layer's forward output (e.mask, same geometry as out)
 // was positive, else 0.
 template <typename TO> struct EpiStoreMask {
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    apply_at(e, N, img, ml, epi_out_base(e, img, ml), n0, v);
+  }
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int, int, long long base, int n0, float* v) {
     const int nvalid = N - n0;
     if (nvalid <= 0) return;
-    const long long idx = (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
+    const long long idx = base + n0;
     const TO* m = (const TO*)e.mask + idx;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -163,9 +181,12 @@ template <typename TO> struct EpiStoreMask {
 // column is its neighbour and 8 packed columns give 4 outputs at column n0/2.
 template <typename TO> struct EpiReluMaxout {
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    apply_at(e, N, img, ml, epi_out_base(e, img, ml), n0, v);
+  }
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int img, int, long long base, int n0, float* v) {
     const int nvalid = N - n0;
     if (nvalid <= 0) return;
-    TO* dst = (TO*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + (n0 >> 1);
+    TO* dst = (TO*)e.out + base + (n0 >> 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (2 * i + 1 < nvalid) {
@@ -181,9 +202,12 @@ template <typename TO> struct EpiReluMaxout {
 // out (fp32) += acc : the second contribution to the carried state gradient in BPTT.
 struct EpiAccumF32 {
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    apply_at(e, N, img, ml, epi_out_base(e, img, ml), n0, v);
+  }
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int, int, long long base, int n0, float* v) {
     const int nvalid = N - n0;
     if (nvalid <= 0) return;
-    float* dst = (float*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
+    float* dst = (float*)e.out + base + n0;
     for (int i = 0; i < 8 && i < nvalid; ++i) dst[i] += v[i];
   }
 };
@@ -191,9 +215,12 @@ struct EpiAccumF32 {
 // out (fp32) += acc with global float atomics: split-K partial sums of the wgrad GEMMs.
 struct EpiAtomicAddF32 {
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
+    apply_at(e, N, img, ml, epi_out_base(e, img, ml), n0, v);
+  }
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int, int, long long base, int n0, float* v) {
     const int nvalid = N - n0;
     if (nvalid <= 0) return;
-    float* dst = (float*)e.out + (long long)img * e.out_img_stride + e.out_extra + e.out_tab[ml] + n0;
+    float* dst = (float*)e.out + base + n0;
     for (int i = 0; i < 8 && i < nvalid; ++i) atomicAdd(dst + i, v[i]);
   }
 };
@@ -209,6 +236,9 @@ __device__ __forceinline__ float tanhf_(float x) {
 // (gaze_grcn.py:108-119).  Columns [0,S) are z, [S,2S) are r.  Writes u (fp32)
 // and the candidate conv's operand r*h (T, halo-padded state image).
 template <typename T> struct EpiGruZR {
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int img, int ml, long long, int n0, float* v) {
+    apply(e, N, img, ml, n0, v);
+  }
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
     if (n0 >= N) return;
     const float* xp = e.xpre + (long long)img * e.xpre_img_stride + (long long)ml * e.xpre_ld + e.xpre_col + n0;
@@ -235,6 +265,9 @@ template <typename T> struct EpiGruZR {
 // (gaze_grcn.py:325) for the head.  Writes h' (fp32 state), h' (T, padded, next
 // step's operand) and BN(h') (T, padded head image of frame img*mul+add = b*T+t).
 template <typename T> struct EpiGruC {
+  static __device__ __forceinline__ void apply_at(const EpiParams& e, int N, int img, int ml, long long, int n0, float* v) {
+    apply(e, N, img, ml, n0, v);
+  }
   static __device__ __forceinline__ void apply(const EpiParams& e, int N, int img, int ml, int n0, float* v) {
     if (n0 >= N) return;
     const float* xp = e.xpre + (long long)img * e.xpre_img_stride + (long long)ml * e.xpre_ld + e.xpre_col + n0;

@@ -166,6 +166,7 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
   if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
   {
     static const int abl = getenv("RGP_ABLATE") ? atoi(getenv("RGP_ABLATE")) : 0;
+    if constexpr (sizeof(T) == 2 && (P == 1 || P == 4)) { if (abl == 32) return launch_stagger<T, P, Epi, 32>(p, e, s); }
     if (sizeof(T) == 2 && P == 8 && abl) {
       if (abl == 1) return launch_stagger<T, P, Epi, 1>(p, e, s);
       if (abl == 2) return launch_stagger<T, P, Epi, 2>(p, e, s);
