@@ -52,9 +52,8 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s) {
   p.out = (bf16_t*)(c->ws + c->act_off[1]);
   p.argmax = c->save ? (unsigned char*)(c->ws + c->B[0].argmax_off) : nullptr;
   p.n_windows = n;
-  const long long tiles = (long long)n * C1_TILES_PER_WINDOW;
-  const int grid = (int)std::min<long long>((tiles + 3) / 4, 1024);
-  conv1a_pool_bf16_kernel<<<grid, 256, 0, s>>>(p);
+  // two 4-wave blocks per CU, a multiple of 8 so that every XCD gets the same number of job slots
+  conv1a_pool_bf16_kernel<<<512, 256, C1_SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
@@ -260,9 +259,10 @@ int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for
       d.tap_src = ts;
       d.pack_taps = nt * 4; d.cin_k = 4; d.cin_src = 3;
       d.s_tap = 3LL * l.cout; d.s_c = l.cout; d.s_n = 1;
-      if (dtype == RGP_BF16) {   // dedicated kernel: K = 10 (kz,ky) taps x 16, filter [64][160]
-        d.tap_src.resize(40);
-        d.pack_taps = 40;
+      if (dtype == RGP_BF16) {   // dedicated kernel: K = 27 (kz,ky,kx) taps x 4 padded to 128, filter [64][128]
+        d.tap_src.clear();
+        for (int t = 0; t < C1_K / 4; ++t) d.tap_src.push_back(t < 27 ? t : -1);
+        d.pack_taps = C1_K / 4;
         d.K = C1_K;
       }
     } else {
