@@ -32,7 +32,8 @@ struct StaggerSmem {
   static constexpr int KOFF_OFF = 3 * STAGE_BYTES;           // 144 KiB
   static constexpr int KOFF_MAX = 256;                       // K-chunks (int each)
   static constexpr int ROWINFO_OFF = KOFF_OFF + KOFF_MAX * 4;
-  static constexpr int BYTES = ROWINFO_OFF + BM * 24;        // 151.0 KiB
+  static constexpr int ROWSET = BM * 24;                     // rowin + rowout (8 B) + rowimg + rowml (4 B) per row
+  static constexpr int BYTES = ROWINFO_OFF + 2 * ROWSET;     // 157.0 KiB
 };
 
 template <typename T, int P, class Epi, int ABLATE = 0>
@@ -46,55 +47,66 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_koff = (int*)(smem + StaggerSmem::KOFF_OFF);
-  long long* s_rowin = (long long*)(smem + StaggerSmem::ROWINFO_OFF);
-  int* s_rowimg = (int*)(s_rowin + BM);
-  int* s_rowml = s_rowimg + BM;
-  long long* s_rowout = (long long*)(s_rowml + BM);          // resolved output offset of the row's pooling window
+  // row tables of the current tile and of the next one (two sets, swapped per tile)
+  auto row_in = [&](int set) { return (long long*)(smem + StaggerSmem::ROWINFO_OFF + set * StaggerSmem::ROWSET); };
+  auto row_out = [&](int set) { return row_in(set) + BM; };
+  auto row_img = [&](int set) { return (int*)(row_in(set) + 2 * BM); };
+  auto row_ml = [&](int set) { return row_img(set) + BM; };
 
+  unsigned long long t_entry = 0;
+  if (ABLATE & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry)::"memory");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const bool group_b = wave >= 4;
 
+  // Persistent: the grid is one block per CU and block b takes tiles b, b + gridDim.x, ...  gridDim.x is a
+  // multiple of 8 (or the whole problem), so a block stays on "its" XCD's contiguous range of the tile order.
   const int n_nt = (p.N + BN - 1) / BN;
   const int n_mt = (p.M + BM - 1) / BM;
   const int nwg = n_mt * n_nt;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, y = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-  }
-  const int mt = bid / n_nt, nt = bid % n_nt;
-  const int m0 = mt * BM, n0 = nt * BN;
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = nwg >> 3, r = nwg & 7, x = t & 7, y = t >> 3;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    m0 = (bid / n_nt) * BM;
+    n0 = (bid % n_nt) * BN;
+  };
+  // row r = tid of a tile: image, row in image, operand origin, output offset of its pooling window.  The
+  // look-ups for the NEXT tile are issued at the start of the epilogue and committed to the other table set
+  // at its end, so only the first tile of a block waits on them.
+  struct RowRegs { int img, ml, in_off, out_off; bool valid; };
+  auto row_lookup = [&](int m0) {
+    RowRegs q;
+    int m = m0 + tid;
+    q.valid = m < p.M;
+    if (!q.valid) m = p.M - 1;
+    q.img = m / p.Mw;
+    q.ml = m - q.img * p.Mw;
+    q.in_off = p.in_tab[q.ml];
+    q.out_off = (q.valid && tid % P == 0) ? e.out_tab[q.ml / P] : 0;
+    return q;
+  };
+  auto row_commit = [&](int set, const RowRegs& q) {
+    row_in(set)[tid] = (long long)q.img * p.in_img_stride + q.in_off;
+    row_img(set)[tid] = q.valid ? q.img : -1;
+    row_ml(set)[tid] = q.ml;
+    row_out(set)[tid] = (q.valid && tid % P == 0) ? (long long)q.img * e.out_img_stride + e.out_extra + q.out_off : 0;
+  };
 
-  for (int r = tid; r < BM; r += NT) {
-    int m = m0 + r;
-    const bool valid = m < p.M;
-    if (!valid) m = p.M - 1;
-    const int img = m / p.Mw, ml = m - img * p.Mw;
-    s_rowin[r] = (long long)img * p.in_img_stride + p.in_tab[ml];
-    s_rowimg[r] = valid ? img : -1;
-    s_rowml[r] = ml;
-    s_rowout[r] = (valid && r % P == 0) ? epi_out_base(e, img, ml / P) : 0;
-  }
+  int tile = blockIdx.x;
+  if (tile >= nwg) return;
+  int m0, n0;
+  tile_origin(tile, m0, n0);
+  if (tid < BM) row_commit(0, row_lookup(m0));
   for (int i = tid; i < p.nk; i += NT) s_koff[i] = p.koff[i];
   __syncthreads();
+  int set = 0;
 
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ lrow;
   const char* a_src[A_PER_WAVE];
-#pragma unroll
-  for (int j = 0; j < A_PER_WAVE; ++j) {
-    const int r = (wave * A_PER_WAVE + j) * 8 + lrow;
-    a_src[j] = (const char*)p.A + s_rowin[r] * ESZ + lchunk * 16;
-  }
   const char* b_src[B_PER_WAVE];
-#pragma unroll
-  for (int j = 0; j < B_PER_WAVE; ++j) {
-    const int r = (wave * B_PER_WAVE + j) * 8 + lrow;
-    b_src[j] = (const char*)p.W + ((long long)(n0 + r) * p.K) * ESZ + lchunk * 16;
-  }
 
   auto stage = [&](int st, int kt) {
     char* abuf = smem + st * STAGE;
@@ -133,26 +145,9 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
     }
   };
 
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int frow = lane & 15, fk = lane >> 4;
   const int a_off = (wm * WTM + frow) * 128, b_off = BM * 128 + (wn * WTN + frow) * 128;
   const int pc0 = ((0 * 4 + fk) ^ (frow & 7)) * 16, pc1 = ((1 * 4 + fk) ^ (frow & 7)) * 16;
-
-  // ---- prologue: K-tiles 0 and 1 in flight, tile 0 landed for everybody ----
-  stage(0, 0);
-  if (p.nk > 1) {
-    stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  if (group_b) __builtin_amdgcn_s_barrier();      // run one half-step behind group A
 
   // diagnostic build only (ABLATE & 32): per-wave s_memtime stamps around the phases; sums go to a
   // debug buffer (EpiParams::c_save, unused by the C3D epilogue) that nothing else reads.
@@ -168,7 +163,41 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       t_prev = t;
     }
   };
+
+#pragma clang loop unroll(disable)
+  while (true) {
+  {
+    const long long* s_rowin = row_in(set);
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      const int r = (wave * A_PER_WAVE + j) * 8 + lrow;
+      a_src[j] = (const char*)p.A + s_rowin[r] * ESZ + lchunk * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      const int r = (wave * B_PER_WAVE + j) * 8 + lrow;
+      b_src[j] = (const char*)p.W + ((long long)(n0 + r) * p.K) * ESZ + lchunk * 16;
+    }
+  }
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: K-tiles 0 and 1 in flight, tile 0 landed for everybody ----
+  stage(0, 0);
+  if (p.nk > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (group_b) __builtin_amdgcn_s_barrier();      // run one half-step behind group A
+
   stamp(-1);
+  if (ABLATE & 32) seg[5] += t_start - t_entry;     // dev: prologue (replaces the bar2 column)
   int st = 0;       // stage of K-tile j
 #pragma clang loop unroll(disable)
   for (int j = 0; j < p.nk; ++j) {
@@ -240,10 +269,10 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    stamp(5);
+    stamp(4);
     st = st + 1 == 3 ? 0 : st + 1;
   }
-  if (ABLATE & 32) seg[6] = t_prev - t_start;
+  if (ABLATE & 32) seg[6] += t_prev - t_start;
   if (!group_b) __builtin_amdgcn_s_barrier();
   __syncthreads();
 
@@ -262,6 +291,16 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
   static_assert(NT % CG == 0, "a thread keeps its column group");
   using Bias = EpiBiasSplit<Epi>;
   const int cg = tid % CG;
+  const int next_tile = tile + gridDim.x;
+  int m0n = 0, n0n = 0;
+  RowRegs nxt = {0, 0, 0, 0, false};
+  if (next_tile < nwg) {
+    tile_origin(next_tile, m0n, n0n);
+    if (tid < BM) nxt = row_lookup(m0n);
+  }
+  const int* s_rowimg = row_img(set);
+  const int* s_rowml = row_ml(set);
+  const long long* s_rowout = row_out(set);
   float bias8[8];
   if constexpr (Bias::value) {
 #pragma unroll
@@ -294,8 +333,17 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       Bias::NoBias::apply_at(e, p.N, img, mlp, s_rowout[rt], n0 + cg * 8, v);
     }
   }
+  stamp(7);                                        // seg[7] = everything after the K loop (epilogue)
+  if (next_tile >= nwg) break;
+  if (tid < BM) row_commit(set ^ 1, nxt);
+  __syncthreads();               // the fp32 tile has been read (the stage ring is free) and the next tables are in place
+  if (ABLATE & 32) t_entry = t_prev;
+  set ^= 1;
+  tile = next_tile;
+  m0 = m0n;
+  n0 = n0n;
+  }
   if ((ABLATE & 32) && e.c_save) {
-    stamp(7);                                      // seg[7] = everything after the K loop (epilogue)
     if (lane == 0) {
       unsigned long long* dbg = (unsigned long long*)e.c_save + ((size_t)blockIdx.x * 8 + wave) * 8;
       for (int k = 0; k < 8; ++k) dbg[k] = seg[k];

@@ -150,7 +150,18 @@ int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
     attr_done = true;
   }
   const int n_mt = (p.M + 255) / 256, n_nt = (p.N + 127) / 128;
-  kern<<<dim3(n_mt * n_nt), dim3(512), smem, s>>>(p, e);
+  // persistent: one block per CU walks the tile list (RGP_PERSIST=0: one block per tile, dev comparison)
+  static const int persist = getenv("RGP_PERSIST") ? atoi(getenv("RGP_PERSIST")) : 1;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    RGP_HIP(hipGetDevice(&dev));
+    RGP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu / 8 * 8;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int tiles = n_mt * n_nt;
+  kern<<<dim3(persist ? std::min(tiles, n_cu) : tiles), dim3(512), smem, s>>>(p, e);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
