@@ -58,7 +58,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--n-steps', type=int, default=16, help='RNN timesteps T per clip')
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
-    ap.add_argument('--c3d-chunk', type=int, default=256, help='windows per C3D launch chain')
+    ap.add_argument('--c3d-chunk', type=int, default=1024, help='windows per C3D launch chain')
     ap.add_argument('--graph', action='store_true', help='train workload: replay the step as HIP graphs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')

@@ -338,7 +338,7 @@ template <int P> __device__ __forceinline__ void pool_window_argmax(const float*
 template <int BM, int BN> struct IgemmSmem {
   static constexpr int TILE_BYTES = (BM + BN) * 128;
   static constexpr int ROWINFO_OFF = 2 * TILE_BYTES;
-  static constexpr int BYTES = ROWINFO_OFF + BM * 16;   // int64 rowin + int img + int ml per row
+  static constexpr int BYTES = ROWINFO_OFF + BM * 24;   // int64 rowin + int img + int ml + int64 rowout per row
 };
 
 // G = K-subchunks per 128-byte chunk that carry their own tap offset (1 for
@@ -359,6 +359,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   long long* s_rowin = (long long*)(smem + IgemmSmem<BM, BN>::ROWINFO_OFF);
   int* s_rowimg = (int*)(s_rowin + BM);
   int* s_rowml = s_rowimg + BM;
+  long long* s_rowout = (long long*)(s_rowml + BM);   // output offset of the row's pooling window, resolved here
+                                                      // so that no epilogue item waits on a table look-up
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     s_rowin[r] = (long long)img * p.in_img_stride + p.in_tab[ml];
     s_rowimg[r] = valid ? img : -1;
     s_rowml[r] = ml;
+    s_rowout[r] = (valid && r % P == 0) ? epi_out_base(e, img, ml / P) : 0;
   }
   __syncthreads();
 
@@ -490,6 +493,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   static_assert(WTM * LDS_LD * 4 <= 2 * TILE_BYTES, "staging fits in the tile buffers");
   constexpr int CG = BN / 8;
   constexpr int ITEMS = (WTM / P) * CG;
+  // a thread keeps its column group over all items when NT % CG == 0: its bias is fetched once, up front
+  using Bias = EpiBiasSplit<Epi>;
+  constexpr bool HOIST = Bias::value && (NT % CG == 0);
+  float bias8[8];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias8[i] = (n0 + (tid % CG) * 8 + i < p.N) ? e.bias[n0 + (tid % CG) * 8 + i] : 0.f;
+  }
 #pragma unroll 1
   for (int slab = 0; slab < WM; ++slab) {
     if (wm == slab) {
@@ -511,7 +522,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
         const float* src = stg + (g * P) * LDS_LD + cg * 8;
         if (P > 1 && e.argmax && n0 + cg * 8 < p.N) pool_window_argmax<P>(src, LDS_LD, v, e.argmax + ((long long)img * (p.Mw / P) + s_rowml[rt] / P) * p.N + n0 + cg * 8);
         else pool_window<P>(src, LDS_LD, v);
-        Epi::apply(e, p.N, img, s_rowml[rt] / P, n0 + cg * 8, v);
+        if constexpr (HOIST) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += bias8[i];
+          Bias::NoBias::apply_at(e, p.N, img, s_rowml[rt] / P, s_rowout[rt], n0 + cg * 8, v);
+        } else {
+          Epi::apply_at(e, p.N, img, s_rowml[rt] / P, s_rowout[rt], n0 + cg * 8, v);
+        }
       }
     }
     __syncthreads();
