@@ -92,3 +92,37 @@ np.save(sys.argv[1], f.cpu().numpy())
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append(np.load(tf.name))
     assert rel_err(outs[1], outs[0]) < 2e-2 and np.isfinite(outs[1]).all()
+
+
+@pytest.mark.parametrize('env,exact', [({'RGP_PERSIST': '0'}, True), ({'RGP_TILE': '0'}, False)])
+def test_persistent_tile_loop_ragged(gpu, env, exact):
+    """85 windows: conv4a has 66 640 rows = 260.3 row tiles, so the persistent staggered kernel walks several
+    tiles per block and ends on a partially valid one.  One block per tile (RGP_PERSIST=0) must give the same
+    bits; the 128x128 tile loop the same values within bf16 tolerance."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from recurrent_gaze_prediction_amd import synthetic as syn
+from recurrent_gaze_prediction_amd.engine import C3DEngine
+eng = C3DEngine(85, dtype='bf16'); eng.set_weights(syn.c3d_params(21))
+torch.manual_seed(5)
+v = torch.rand(85, 16, 112, 112, 3, device='cuda') - 0.5
+f, _ = eng.forward(v); torch.cuda.synchronize()
+np.save(sys.argv[1], f.cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for e in ({}, env):
+        with tempfile.NamedTemporaryFile(suffix='.npy') as tf:
+            r = subprocess.run([sys.executable, '-c', code, tf.name], env=dict(os.environ, **e), capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(np.load(tf.name))
+    assert np.isfinite(outs[1]).all() and np.abs(outs[0]).max() > 0
+    if exact:
+        assert np.array_equal(outs[0], outs[1])
+    else:
+        assert rel_err(outs[1], outs[0]) < 2e-2
