@@ -52,7 +52,7 @@ constexpr int C1_NLD = (C1_CHUNKS + 255) / 256;           // 7 loads per thread
 constexpr int C1_TILES = C1_JROWS * C1_XG;                // 28 wave tiles per job
 constexpr int C1_SMEM = 2 * C1_PATCH + 4 * 8 * 72 * 2 + 4 * 8 * 72;
 
-__global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aParams p) {
+static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aParams p) {
   extern __shared__ __attribute__((aligned(16))) char c1_smem[];
   char* patch = c1_smem;                                                   // [2][C1_PATCH]
   bf16_t* s_out = (bf16_t*)(c1_smem + 2 * C1_PATCH);                       // per wave: 8 px x (64 ch + 8 pad)

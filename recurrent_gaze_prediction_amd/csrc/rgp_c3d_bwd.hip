@@ -14,6 +14,7 @@
 
 #include "rgp_c3d_plan.h"
 #include "wgrad_launch.h"
+#include "conv1a_wgrad.hip.h"
 
 using namespace rgp;
 
@@ -160,7 +161,24 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       p.ldw = l.cout;
       p.k_valid = c->L[i].nk * Elem<T>::BKE;
       p.steps_per_split = 0;
-      if (i == 0) {
+      if (i == 0 && sizeof(T) == 2) {
+        // dedicated kernel: filter + bias gradient straight from the pooled gradient and the arg-max codes
+        Conv1aWgradParams q;
+        q.in = (const bf16_t*)(ws + c->act_off[0]);
+        q.dyp = (const bf16_t*)(ws + c->dyp_off);
+        q.argmax = (const unsigned char*)(ws + b.argmax_off);
+        q.y = (const bf16_t*)(ws + c->act_off[1]);
+        q.dw = grads + b.grad_w;
+        q.db = grads + b.grad_b;
+        q.n_windows = n;
+        static bool attr_done = false;
+        if (!attr_done) {
+          RGP_HIP(hipFuncSetAttribute((const void*)conv1a_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W1_SMEM));
+          attr_done = true;
+        }
+        conv1a_wgrad_bf16_kernel<<<256, 512, W1_SMEM, s>>>(q);
+        RGP_HIP(hipGetLastError());
+      } else if (i == 0) {
         p.dW = (float*)(ws + c->dw1_off);
         RGP_HIP(hipMemsetAsync(p.dW, 0, (size_t)p.nk * Elem<T>::BKE * 64 * 4, s));
         RGP_TRY((launch_wgrad<T, G0>(p, s)));
@@ -181,7 +199,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       const C3dLayerSpec& ll = kLayers[i - 1];
       const int PR = (ll.D / ll.pd) * (ll.H / ll.ph) * (ll.H / ll.ph);
       const long long rows = (long long)n * PR;
-      unpool_kernel<T><<<blocks_for(rows, 256 / (ll.cout / 8) * 8), 256, 0, s>>>(
+      // bf16 conv1a consumes the pooled gradient directly (conv1a_wgrad.hip.h): its 6.4 MB-per-window dY image is
+      // only built on demand by rgp_c3d_read_grad_image
+      if (!(i == 1 && sizeof(T) == 2)) unpool_kernel<T><<<blocks_for(rows, 256 / (ll.cout / 8) * 8), 256, 0, s>>>(
           (const T*)(ws + c->dyp_off), (const unsigned char*)(ws + lo.argmax_off), (const T*)(ws + c->act_off[i]),
           (const int*)(ws + c->unpad_off[i - 1]), c->act_stride[i], (T*)(ws + lo.dypre_off), (const int*)(ws + lo.win_tab_off),
           (const int*)(ws + lo.q_off_off), lo.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, rows, grads + lo.grad_b);
@@ -308,6 +328,19 @@ int rgp_c3d_read_grad_image(rgp_c3d_t* c, int layer, int n_windows, float* dst, 
   const long long total = (long long)n_windows * rows * C;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
   const int* tab = (const int*)(c->ws + b.y_tab_off);
+  if (layer == 0 && c->dtype == RGP_BF16) {
+    // the backward pass kept only the pooled gradient of conv1a (still in the dyp buffer: pool1 is the last pooled
+    // layer it visits); expand it now.  The bias sums of this pass go to a scratch area.
+    const C3dLayerSpec& ll = kLayers[0];
+    const int PR = (ll.D / ll.pd) * (ll.H / ll.ph) * (ll.H / ll.ph);
+    const long long prow = (long long)n_windows * PR;
+    RGP_HIP(hipMemsetAsync(c->ws + b.dypre_off, 0, (size_t)n_windows * b.dypre_stride * 2, s));
+    unpool_kernel<bf16_t><<<(int)std::min<long long>((prow + 255) / 256, 4096), 256, 0, s>>>(
+        (const bf16_t*)(c->ws + c->dyp_off), (const unsigned char*)(c->ws + b.argmax_off), (const bf16_t*)(c->ws + c->act_off[1]),
+        (const int*)(c->ws + c->unpad_off[0]), c->act_stride[1], (bf16_t*)(c->ws + b.dypre_off), (const int*)(c->ws + b.win_tab_off),
+        (const int*)(c->ws + b.q_off_off), b.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, prow, (float*)(c->ws + c->dw1_off));
+    RGP_HIP(hipGetLastError());
+  }
   if (c->dtype == RGP_BF16)
     unpad_kernel<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)(c->ws + b.dypre_off), dst, tab, rows, C, b.dypre_stride, total);
   else
