@@ -10,9 +10,11 @@
 // gradients of the recurrence are hoisted out of the time loop (one GEMM over all T steps),
 // so BPTT itself is 2 dgrad convs + 2 element-wise kernels per step.
 #include <algorithm>
+#include <cstring>
 
 #include "bwd_kernels.hip.h"
 #include "rgp_grcn_plan.h"
+#include "wgrad_launch.h"
 
 using namespace rgp;
 
@@ -20,12 +22,11 @@ struct GrcnBwd {
   ConvDesc b_d2, b_d1, b_c, b_zr, b_x;     // dgrad convolutions
   ConvDesc b_px;                           // projection input gradient: d rows = dE x W^T
   // gather tables [ntaps][Mw] (element offsets, -1 = zero) + offsets in the workspace
-  std::vector<int> t_E9, t_h9, t_dd1, t_dd2, t_y, t_d1, t_pad3S, t_pad2S, t_zero1, koff_m, koff_m2;
-  size_t o_E9 = 0, o_h9 = 0, o_dd1 = 0, o_dd2 = 0, o_y = 0, o_d1 = 0, o_pad3S = 0, o_pad2S = 0,
-         o_zero1 = 0, o_koff_m = 0, o_koff_m2 = 0;
+  std::vector<int> t_y, t_pad3S, t_pad2S, koff_c;
+  size_t o_y = 0, o_pad3S = 0, o_pad2S = 0, o_koff_c = 0;
   long long M = 0, M2 = 0, Mp = 0, M2p = 0;
   Buf dz, frame_sum, dgp, gp, dd2, dd1, dy, dh_head, dh_carry, drh, dcp_pad, dzr_pad, dxpre, dxpre_pad, dE, rh_all;
-  Buf xT, dET, EcolT, dXpreT, HcolT, RHcolT, dd1colT, yT, dd2colT, d1T, sq_partial;
+  Buf hp_all, rhp_all, sq_partial;     // halo-padded h_{t-1} and r.h_{t-1} of every step, [t][b][9][9][S] (wgrad operands)
   rgp_grcn_weights w;   // forward weights (device fp32) as last set
 };
 
@@ -35,45 +36,24 @@ constexpr int SQ_BLOCKS = 256;
 
 size_t put(Arena& a, const std::vector<int>& t) { return a.take(t.size() * 4); }
 
-template <typename TS, typename TD>
-int gather_T(const TS* src, TD* dst, const int* tab, int ntaps, int Mw, long long M, int C, long long ld, int row0,
-             int inner, long long s_in, long long s_out, hipStream_t s) {
-  dim3 grid((unsigned)((M + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)ntaps);
-  gather_transpose_kernel<TS, TD><<<grid, 256, 0, s>>>(src, dst, tab, Mw, M, C, ld, row0, inner, s_in, s_out);
-  RGP_HIP(hipGetLastError());
-  return RGP_OK;
-}
-
-// dW[rows x N] (+)= AT[rows x Kp] * BT[N x Kp]^T, K-contiguous operands, split-K atomics.
+// out[c] += sum over rows of x[r][c]; thread = (row lane, 8-column group), one atomic per column and block
 template <typename T>
-int wgrad_gemm(const rgp_grcn* g, const T* AT, int rows, const T* BT, int N, long long Kp, size_t koff_off, float* out,
-               hipStream_t s) {
-  const GrcnBwd* b = g->bwd;
-  IgemmParams p;
-  p.A = AT;
-  p.W = BT;
-  p.in_tab = (const int*)(g->ws + b->o_zero1);
-  p.koff = (const int*)(g->ws + koff_off);
-  p.in_img_stride = Kp;
-  p.Mw = 1;
-  p.M = rows;
-  p.N = N;
-  p.K = (int)Kp;
-  p.nk = (int)(Kp / Elem<T>::BKE);
-  EpiParams e;
-  memset(&e, 0, sizeof(e));
-  e.out = out;
-  e.out_tab = (const int*)(g->ws + b->o_zero1);
-  e.out_img_stride = N;
-  const int tiles = ((rows + 127) / 128) * ((N + 127) / 128);
-  // split-K: every split adds rows x N fp32 atomics (the 1024-block rule used before spent 40 % of config 4's
-  // training step in these GEMMs).  Measured optimum on MI355X: ~128 blocks in total for short reductions
-  // (B*T*49 = 13.7 k rows: 7.3 -> 5.1 ms per step), ~256 for long ones (50 k rows: 9.9 -> 7.7 ms); RGP_WG_BLOCKS overrides.
-  static const int target_env = getenv("RGP_WG_BLOCKS") ? atoi(getenv("RGP_WG_BLOCKS")) : 0;
-  const int target = target_env > 0 ? target_env : (p.nk > 400 ? 256 : 128);
-  int ksplit = std::max(1, std::min(target / std::max(tiles, 1), p.nk / 8));
-  ksplit = std::max(1, std::min(ksplit, 64));
-  return launch_igemm<T, 1, 1, EpiAtomicAddF32>(p, e, s, ksplit);
+__global__ __launch_bounds__(256) void dense_colsum_kernel(const T* __restrict__ x, long long rows, int C, float* __restrict__ out) {
+  __shared__ float red[256 * 8];
+  const int CG = C / 8, cg = threadIdx.x % CG, rl = threadIdx.x / CG, RL = 256 / CG;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long r = (long long)blockIdx.x * RL + rl; r < rows; r += (long long)gridDim.x * RL) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += Elem<T>::from(x[r * C + cg * 8 + k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rl * C + cg * 8 + k] = a[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += red[r * C + c];
+    atomicAdd(out + c, t);
+  }
 }
 
 template <typename T>
@@ -82,7 +62,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   GrcnBwd* b = g->bwd;
   char* ws = g->ws;
   const int B = g->B, T_ = g->T, S = g->S, P = g->P, F = g->F;
-  const long long M = b->M, Mp = b->Mp, M2 = b->M2, M2p = b->M2p;
+  const long long M = b->M, M2 = b->M2;
+  auto wg_params = []() { WgradParams p; memset(&p, 0, sizeof(p)); return p; };
   const size_t st = (size_t)B * 49 * S;
   auto I = [&](size_t off) { return (const int*)(ws + off); };
   auto Fp = [&](const Buf& x) { return (float*)(ws + x.off); };
@@ -90,6 +71,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
 
   // zero the gradients that are accumulated with atomics
   RGP_HIP(hipMemsetAsync((void*)gr->proj_c3d_W, 0, (size_t)1024 * P * 4, s));
+  RGP_HIP(hipMemsetAsync((void*)gr->proj_c3d_b, 0, (size_t)P * 4, s));
+  RGP_HIP(hipMemsetAsync(ws + b->dE.off, 0, (size_t)P * sizeof(T), s));                    // dE's zero row
   for (const float* q : {gr->gru_Wz, gr->gru_Wr, gr->gru_W}) RGP_HIP(hipMemsetAsync((void*)q, 0, (size_t)9 * P * S * 4, s));
   for (const float* q : {gr->gru_Uz, gr->gru_Ur, gr->gru_U}) RGP_HIP(hipMemsetAsync((void*)q, 0, (size_t)9 * S * S * 4, s));
   RGP_HIP(hipMemsetAsync((void*)gr->up_weight1, 0, (size_t)25 * 64 * S * 4, s));
@@ -113,9 +96,16 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   head_fold_dgrad_kernel<T><<<dim3(49, F), 256, 0, s>>>(Fp(b->dz), Fp(b->gp), Tp(b->dd2));
   RGP_HIP(hipGetLastError());
   // 3. deconv2: wgrad (dF2[a,b,o,c] = sum dd2[2i+a,2j+b,o] d1[i,j,c]) and dgrad
-  RGP_TRY((gather_T<T, T>(Tp(b->dd2), Tp(b->dd2colT), I(b->o_dd2), 25, 529, M2, 32, M2p, 0, 1, 0, 2401LL * 32, s)));
-  RGP_TRY((gather_T<T, T>(Tp(g->D1), Tp(b->d1T), I(b->o_d1), 1, 529, M2, 64, M2p, 0, 1, 0, 27LL * 27 * 64, s)));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->dd2colT), 25 * 32, Tp(b->d1T), 64, M2p, b->o_koff_m2, (float*)gr->up_weight2, s));
+  {  // rows = the 23x23 positions of d1; X = dd2 at the stride-2 row origins (taps of b_d2), dY = the padded d1 image
+    WgradParams p = wg_params();
+    p.X = Tp(b->dd2); p.dY = Tp(g->D1); p.dW = (float*)gr->up_weight2;
+    wgrad_grid(p, 1, 23, 23);
+    p.x_sx = 2 * 32; p.x_sy = 2 * 49 * 32; p.x_img_stride = 2401LL * 32;
+    p.y_sx = 64; p.y_sy = 27 * 64; p.y_org = (2 * 27 + 2) * 64; p.y_img_stride = 27LL * 27 * 64;
+    p.koff = I(b->b_d2.koff_off); p.M = M2; p.N = 64; p.nk = b->b_d2.nk; p.ldw = 64; p.k_valid = 25 * 32;
+    if (sizeof(T) == 2) RGP_TRY((launch_wgrad<T, 2>(p, s)));
+    else RGP_TRY((launch_wgrad<T, 1>(p, s)));
+  }
   {
     IgemmParams p = make_params(b->b_d2, Tp(b->dd2), ws, F);
     EpiParams e = make_epi(b->b_d2, Tp(b->dd1), ws);
@@ -123,9 +113,15 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     else RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
   }
   // 4. deconv1: wgrad (dF1[a,b,o,c] = sum dd1[3i+a,3j+b,o] y[i,j,c]) and dgrad -> dy (fp32)
-  RGP_TRY((gather_T<T, T>(Tp(b->dd1), Tp(b->dd1colT), I(b->o_dd1), 25, 49, M, 64, Mp, 0, 1, 0, 529LL * 64, s)));
-  RGP_TRY((gather_T<T, T>(Tp(g->hbn), Tp(b->yT), I(b->o_y), 1, 49, M, S, Mp, 0, 1, 0, 81LL * S, s)));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->dd1colT), 25 * 64, Tp(b->yT), S, Mp, b->o_koff_m, (float*)gr->up_weight1, s));
+  {  // rows = the 7x7 positions of y; X = dd1 at the stride-3 row origins (taps of b_d1), dY = the padded BN(h) image
+    WgradParams p = wg_params();
+    p.X = Tp(b->dd1); p.dY = Tp(g->hbn); p.dW = (float*)gr->up_weight1;
+    wgrad_grid(p, 1, 7, 7);
+    p.x_sx = 3 * 64; p.x_sy = 3 * 23 * 64; p.x_img_stride = 529LL * 64;
+    p.y_sx = S; p.y_sy = 9 * S; p.y_org = 10 * S; p.y_img_stride = 81LL * S;
+    p.koff = I(b->b_d1.koff_off); p.M = M; p.N = S; p.nk = b->b_d1.nk; p.ldw = S; p.k_valid = 25 * 64;
+    RGP_TRY((launch_wgrad<T, 1>(p, s)));
+  }
   {
     IgemmParams p = make_params(b->b_d1, Tp(b->dd1), ws, F);
     EpiParams e = make_epi(b->b_d1, Fp(b->dy), ws);
@@ -165,29 +161,53 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
                                                                                       I(b->o_pad3S), tot, 3 * S);
     RGP_HIP(hipGetLastError());
     IgemmParams p = make_params(b->b_x, Tp(b->dxpre_pad), ws, F);
-    EpiParams e = make_epi(b->b_x, Tp(b->dE), ws);
+    EpiParams e = make_epi(b->b_x, Tp(b->dE) + P, ws);        // row 0 of the buffer stays zero (wgrad_kernel's dY contract)
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
   }
-  // 8. weight gradients of the recurrence and the projection, hoisted over all T steps
-  RGP_TRY((gather_T<float, T>(Fp(b->dxpre), Tp(b->dXpreT), I(b->o_zero1), 1, 1, M, 3 * S, Mp, 0, 1, 0, 3LL * S, s)));
-  RGP_TRY((gather_T<T, T>(Tp(g->E), Tp(b->EcolT), I(b->o_E9), 9, 49, M, P, Mp, 0, 1, 0, 81LL * P, s)));
-  // h_{t-1} of frame (b,t) is hall[t][b]; frames are b-major: img = b*T+t -> (img % T)*B*49*S + (img / T)*49*S
-  RGP_TRY((gather_T<float, T>(Fp(g->hall), Tp(b->HcolT), I(b->o_h9), 9, 49, M, S, Mp, 0, T_, (long long)st, 49LL * S, s)));
-  mul_kernel<<<(int)std::min<size_t>((st * T_ + 255) / 256, 8192), 256, 0, s>>>(Fp(g->rall), Fp(g->hall), Fp(b->rh_all), (long long)st * T_);
-  RGP_HIP(hipGetLastError());
-  RGP_TRY((gather_T<float, T>(Fp(b->rh_all), Tp(b->RHcolT), I(b->o_h9), 9, 49, M, S, Mp, 0, T_, (long long)st, 49LL * S, s)));
-  RGP_TRY((gather_T<T, T>(Tp(b->dE), Tp(b->dET), I(b->o_zero1), 1, 1, M, P, Mp, 0, 1, 0, (long long)P, s)));
-  RGP_TRY((gather_T<T, T>(Tp(g->xt), Tp(b->xT), I(b->o_zero1), 1, 1, M, 1024, Mp, 0, 1, 0, 1024LL, s)));
-  const T* dXT = Tp(b->dXpreT);
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->EcolT), 9 * P, dXT, S, Mp, b->o_koff_m, (float*)gr->gru_Wz, s));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->EcolT), 9 * P, dXT + (size_t)S * Mp, S, Mp, b->o_koff_m, (float*)gr->gru_Wr, s));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->EcolT), 9 * P, dXT + (size_t)2 * S * Mp, S, Mp, b->o_koff_m, (float*)gr->gru_W, s));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->HcolT), 9 * S, dXT, S, Mp, b->o_koff_m, (float*)gr->gru_Uz, s));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->HcolT), 9 * S, dXT + (size_t)S * Mp, S, Mp, b->o_koff_m, (float*)gr->gru_Ur, s));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->RHcolT), 9 * S, dXT + (size_t)2 * S * Mp, S, Mp, b->o_koff_m, (float*)gr->gru_U, s));
-  RGP_TRY(wgrad_gemm<T>(g, Tp(b->xT), 1024, Tp(b->dET), P, Mp, b->o_koff_m, (float*)gr->proj_c3d_W, s));
-  rowsum_kernel<T><<<P, 256, 0, s>>>(Tp(b->dET), (float*)gr->proj_c3d_b, Mp, M);
-  RGP_HIP(hipGetLastError());
+  // 8. weight gradients of the recurrence and the projection, hoisted over all T steps: wgrad_kernel straight on the
+  //    halo-padded operand images (no im2col / transposed copies).  Gate g's gradient columns are [gS, (g+1)S) of the
+  //    padded dxpre image.
+  {
+    const long long tot = (long long)T_ * B * 49 * S;
+    const int nb = (int)std::min<long long>((tot + 255) / 256, 8192);
+    mul_kernel<<<nb, 256, 0, s>>>(Fp(g->rall), Fp(g->hall), Fp(b->rh_all), tot);
+    pad_rows_kernel<T><<<nb, 256, 0, s>>>(Fp(g->hall), Tp(b->hp_all), I(b->o_y), tot, S);       // h_{t-1}, [t][b][9][9][S]
+    pad_rows_kernel<T><<<nb, 256, 0, s>>>(Fp(b->rh_all), Tp(b->rhp_all), I(b->o_y), tot, S);   // r . h_{t-1}
+    RGP_HIP(hipGetLastError());
+    WgradParams p = wg_params();
+    p.y_sx = 3 * S; p.y_sy = 27 * S; p.y_org = 30 * S;
+    p.N = S; p.ldw = S; p.M = M;
+    // input filters: rows = frames x 7x7, X = the padded projected features E
+    wgrad_grid(p, 1, 7, 7);
+    p.X = Tp(g->E); p.x_sx = P; p.x_sy = 9 * P; p.x_img_stride = 81LL * P; p.y_img_stride = 243LL * S;
+    p.koff = I(g->xconv.koff_off); p.nk = g->xconv.nk; p.k_valid = 9 * P;
+    float* dWx[3] = {(float*)gr->gru_Wz, (float*)gr->gru_Wr, (float*)gr->gru_W};
+    for (int q = 0; q < 3; ++q) {
+      p.dY = Tp(b->dxpre_pad) + q * S; p.dW = dWx[q];
+      RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    }
+    // recurrent filters: image = clip b, z = step t (h images are step-major, gradient frames clip-major)
+    wgrad_grid(p, T_, 7, 7);
+    p.x_sx = S; p.x_sy = 9 * S; p.x_sz = B * 81 * S; p.x_img_stride = 81LL * S;
+    p.y_sz = 243 * S; p.y_img_stride = (long long)T_ * 243 * S;
+    p.koff = I(g->gzr.koff_off); p.nk = g->gzr.nk; p.k_valid = 9 * S;
+    float* dWh[3] = {(float*)gr->gru_Uz, (float*)gr->gru_Ur, (float*)gr->gru_U};
+    for (int q = 0; q < 3; ++q) {
+      p.X = q < 2 ? Tp(b->hp_all) : Tp(b->rhp_all);
+      p.dY = Tp(b->dxpre_pad) + q * S; p.dW = dWh[q];
+      RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    }
+  }
+  {  // projection: one row per (frame, position), X = the 1024-channel C3D rows, dY = dE behind its zero row
+    WgradParams p = wg_params();
+    p.X = Tp(g->xt); p.dY = Tp(b->dE); p.dW = (float*)gr->proj_c3d_W;
+    wgrad_grid(p, 1, 1, (int)M);
+    p.x_sx = 1024; p.y_sx = P; p.y_org = P;
+    p.koff = I(b->o_koff_c); p.M = M; p.N = P; p.nk = 1024 / Elem<T>::BKE; p.ldw = P; p.k_valid = 1024;
+    RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    dense_colsum_kernel<T><<<(int)std::min<long long>((M + 63) / 64, 1024), 256, 0, s>>>(Tp(b->dE) + P, M, P, (float*)gr->proj_c3d_b);
+    RGP_HIP(hipGetLastError());
+  }
   return RGP_OK;
 }
 
@@ -274,31 +294,14 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   if (!ok) return set_err(RGP_EINVAL, "rgp_grcn_create: backward K schedule failed");
   for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) d->reserve(a, dtype);
 
-  // ---- gather tables
-  for (int t = 0; t < 9; ++t) for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x) {
-    const int ky = t / 3, kx = t % 3;
-    b->t_E9.push_back(((y + ky) * 9 + x + kx) * P);
-    const int yy = y + ky - 1, xx = x + kx - 1;
-    b->t_h9.push_back((yy >= 0 && yy < 7 && xx >= 0 && xx < 7) ? (yy * 7 + xx) * S : -1);
-  }
-  for (int aa = 0; aa < 5; ++aa) for (int bb = 0; bb < 5; ++bb) {
-    for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) b->t_dd1.push_back(((3 * i + aa) * 23 + 3 * j + bb) * 64);
-  }
-  for (int aa = 0; aa < 5; ++aa) for (int bb = 0; bb < 5; ++bb) {
-    for (int i = 0; i < 23; ++i) for (int j = 0; j < 23; ++j) b->t_dd2.push_back(((2 * i + aa) * 49 + 2 * j + bb) * 32);
-  }
+  // ---- small tables
   for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x) {
     b->t_y.push_back(((y + 1) * 9 + x + 1) * S);            // interior of a 9x9xS image
     b->t_pad3S.push_back(((y + 1) * 9 + x + 1) * 3 * S);    // interior of a 9x9x3S image
     b->t_pad2S.push_back(((y + 1) * 9 + x + 1) * 2 * S);    // interior of a 9x9x2S image
   }
-  for (int i = 0; i < 23; ++i) for (int j = 0; j < 23; ++j) b->t_d1.push_back(((i + 2) * 27 + j + 2) * 64);
-  b->t_zero1.push_back(0);
-  for (long long k = 0; k < b->Mp / 32; ++k) b->koff_m.push_back((int)(k * bke(dtype)));
-  for (long long k = 0; k < b->M2p / 32; ++k) b->koff_m2.push_back((int)(k * bke(dtype)));
-  b->o_E9 = put(a, b->t_E9); b->o_h9 = put(a, b->t_h9); b->o_dd1 = put(a, b->t_dd1); b->o_dd2 = put(a, b->t_dd2);
-  b->o_y = put(a, b->t_y); b->o_d1 = put(a, b->t_d1); b->o_pad3S = put(a, b->t_pad3S); b->o_pad2S = put(a, b->t_pad2S);
-  b->o_zero1 = put(a, b->t_zero1); b->o_koff_m = put(a, b->koff_m); b->o_koff_m2 = put(a, b->koff_m2);
+  for (int k = 0; k < 1024 / bke(dtype); ++k) b->koff_c.push_back(k * bke(dtype));
+  b->o_y = put(a, b->t_y); b->o_pad3S = put(a, b->t_pad3S); b->o_pad2S = put(a, b->t_pad2S); b->o_koff_c = put(a, b->koff_c);
 
   // ---- buffers
   const size_t st = (size_t)B * 49 * S * 4;
@@ -316,19 +319,10 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   b->dzr_pad = take(a, (size_t)B * 81 * 2 * S * es);
   b->dxpre = take(a, (size_t)F * 49 * 3 * S * 4);
   b->dxpre_pad = take(a, (size_t)F * 81 * 3 * S * es);
-  b->dE = take(a, (size_t)b->M * P * es);
+  b->dE = take(a, (size_t)(b->M + 1) * P * es);        // + a leading zero row
   b->rh_all = take(a, st * T_);
-  auto rows128 = [](int n) { return (size_t)((n + 127) / 128 * 128 + 128); };
-  b->xT = take(a, rows128(1024) * b->Mp * es);
-  b->dET = take(a, rows128(P) * b->Mp * es);
-  b->EcolT = take(a, rows128(9 * P) * b->Mp * es);
-  b->dXpreT = take(a, rows128(3 * S) * b->Mp * es);
-  b->HcolT = take(a, rows128(9 * S) * b->Mp * es);
-  b->RHcolT = take(a, rows128(9 * S) * b->Mp * es);
-  b->dd1colT = take(a, rows128(25 * 64) * b->Mp * es);
-  b->yT = take(a, rows128(S) * b->Mp * es);
-  b->dd2colT = take(a, rows128(25 * 32) * b->M2p * es);
-  b->d1T = take(a, rows128(64) * b->M2p * es);
+  b->hp_all = take(a, (size_t)T_ * B * 81 * S * es);
+  b->rhp_all = take(a, (size_t)T_ * B * 81 * S * es);
   b->sq_partial = take(a, SQ_BLOCKS * 4);
   return RGP_OK;
 }
@@ -340,9 +334,8 @@ int grcn_bwd_upload(rgp_grcn* g, hipStream_t s) {
     RGP_HIP(hipMemcpyAsync(g->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
     return RGP_OK;
   };
-  RGP_TRY(up(b->t_E9, b->o_E9)); RGP_TRY(up(b->t_h9, b->o_h9)); RGP_TRY(up(b->t_dd1, b->o_dd1)); RGP_TRY(up(b->t_dd2, b->o_dd2));
-  RGP_TRY(up(b->t_y, b->o_y)); RGP_TRY(up(b->t_d1, b->o_d1)); RGP_TRY(up(b->t_pad3S, b->o_pad3S)); RGP_TRY(up(b->t_pad2S, b->o_pad2S));
-  RGP_TRY(up(b->t_zero1, b->o_zero1)); RGP_TRY(up(b->koff_m, b->o_koff_m)); RGP_TRY(up(b->koff_m2, b->o_koff_m2));
+  RGP_TRY(up(b->t_y, b->o_y)); RGP_TRY(up(b->t_pad3S, b->o_pad3S)); RGP_TRY(up(b->t_pad2S, b->o_pad2S));
+  RGP_TRY(up(b->koff_c, b->o_koff_c));
   return RGP_OK;
 }
 
@@ -394,7 +387,7 @@ int rgp_grcn_backward_input(rgp_grcn_t* g, float* d_rows, rgp_stream_t stream) {
   if (!g->ws || !g->save || !g->bwd || !g->weights_set) return set_err(RGP_ESTATE, "rgp_grcn_backward_input: call after rgp_grcn_backward");
   hipStream_t s = (hipStream_t)stream;
   GrcnBwd* b = g->bwd;
-  IgemmParams p = make_params(b->b_px, g->ws + b->dE.off, g->ws, (int)b->M);
+  IgemmParams p = make_params(b->b_px, g->ws + b->dE.off + (size_t)g->P * esize(g->dtype), g->ws, (int)b->M);
   EpiParams e = make_epi(b->b_px, d_rows, g->ws);
   return g->dtype == RGP_BF16 ? launch_igemm<bf16_t, 1, 1, EpiStore<float, false, false>>(p, e, s)
                               : launch_igemm<float, 1, 1, EpiStore<float, false, false>>(p, e, s);
