@@ -62,6 +62,18 @@ static __global__ void fold_head_filter_kernel(const float* __restrict__ f, cons
   g[i] = s;
 }
 
+// Row-Toeplitz form of the folded head filter g[tap = a*7+b][c] (rgp_grcn.hip run_d3):
+//   gt[u][n][x'*32 + c] = g[(6-u)*7 + 6-(x'-n)][c] for 0 <= x'-n <= 6, else 0;   bias16[n] = out_b
+static __global__ void toeplitz_head_filter_kernel(const float* __restrict__ g, const float* __restrict__ out_b,
+                                                   float* __restrict__ gt, float* __restrict__ bias16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 16) bias16[i] = out_b[0];
+  if (i >= 7 * 16 * 704) return;
+  const int c = i % 32, xp = (i / 32) % 22, n = (i / 704) % 16, u = i / (16 * 704);
+  const int v = xp - n;
+  gt[i] = (v >= 0 && v <= 6) ? g[((6 - u) * 7 + (6 - v)) * 32 + c] : 0.f;
+}
+
 __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -57,8 +57,19 @@ std::vector<int> pad_tab(int H, int halo, int C) {
 
 size_t put_tab(Arena& a, const std::vector<int>& t) { return a.take(t.size() * 4); }
 
+// logit[y,x] = sum_{u,v,c} D2p[y+u, x+v, c] G[6-u, 6-v, c] + out_b has ONE output channel: as an implicit GEMM over
+// (tap, channel) it fills 1 of the 32 columns of the narrowest tile.  Instead a GEMM row is (y, block of 16 x): for
+// tap row u its operand is the contiguous run D2p[y+u, x0 .. x0+21, 0..31] (704 elements) and the filter is the
+// Toeplitz matrix Gt[u][(x', c)][n] = G[6-u, 6-(x'-n), c] (0 outside the 7 taps) -- 3.1x the MACs, all 16 columns
+// useful, 5x less MFMA work than before.  49 = 3 x 16 + 1: the last pixel column goes through the 1-column path.
 template <typename T, int G>
 int run_d3(rgp_grcn* g, float* logits, hipStream_t s) {
+  {
+    IgemmParams p = make_params(g->d3t, g->ws + g->D2.off, g->ws, g->F);
+    EpiParams e = make_epi(g->d3t, logits, g->ws);
+    e.bias = (const float*)(g->ws + g->bias16.off);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, true, false>>(p, e, s)));
+  }
   IgemmParams p = make_params(g->d3, g->ws + g->D2.off, g->ws, g->F);
   EpiParams e = make_epi(g->d3, logits, g->ws);
   e.bias = g->out_b;
@@ -182,6 +193,11 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_HIP(hipGetLastError());
   RGP_HIP(hipMemsetAsync(ws + g->d3.w_off, 0, g->d3.w_bytes(g->dtype), s));
   RGP_TRY(pack_filter<T>(g->d3, gf, ws, 1, 0, s));
+  toeplitz_head_filter_kernel<<<(7 * 16 * 704 + 255) / 256, 256, 0, s>>>(gf, w->out_b, (float*)(ws + g->gtoep.off),
+                                                                          (float*)(ws + g->bias16.off));
+  RGP_HIP(hipGetLastError());
+  RGP_HIP(hipMemsetAsync(ws + g->d3t.w_off, 0, g->d3t.w_bytes(g->dtype), s));
+  RGP_TRY(pack_filter<T>(g->d3t, (const float*)(ws + g->gtoep.off), ws, 16, 0, s));
   g->bn_gamma = w->bn_gamma;
   g->bn_beta = w->bn_beta;
   g->proj_b = w->proj_c3d_b;
@@ -256,17 +272,26 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   // (gaze_grcn.py:353-361): logit[y,x] = sum in[y-a+3, x-b+3, c] G[a,b,c] + out_b.
   {
     ConvDesc& d = g->d3;
-    d.Mw = 2401; d.N = 1; d.in_img_stride = 55LL * 55 * 32; d.out_img_stride = 2401;
-    for (int y = 0; y < 49; ++y) for (int x = 0; x < 49; ++x) { d.in_tab.push_back((y * 55 + x) * 32); d.out_tab.push_back(y * 49 + x); }
+    d.Mw = 49; d.N = 1; d.in_img_stride = 55LL * 55 * 32; d.out_img_stride = 2401;     // pixel column x = 48 only
+    for (int y = 0; y < 49; ++y) { d.in_tab.push_back((y * 55 + 48) * 32); d.out_tab.push_back(y * 49 + 48); }
     std::vector<int> tapoff, fidx;
     for (int u = 0; u < 7; ++u) for (int v = 0; v < 7; ++v) { tapoff.push_back((u * 55 + v) * 32); fidx.push_back((6 - u) * 7 + (6 - v)); }
     ok &= build_k_schedule(d, tapoff, fidx, 32, dtype);
     d.s_tap = 32; d.s_n = 0; d.s_c = 1;
   }
+  {  // pixel columns 0..47 in blocks of 16 (run_d3)
+    ConvDesc& d = g->d3t;
+    d.Mw = 49 * 3; d.N = 16; d.in_img_stride = 55LL * 55 * 32; d.out_img_stride = 2401;
+    for (int y = 0; y < 49; ++y) for (int xb = 0; xb < 3; ++xb) { d.in_tab.push_back((y * 55 + 16 * xb) * 32); d.out_tab.push_back(y * 49 + 16 * xb); }
+    std::vector<int> tapoff, fidx;
+    for (int u = 0; u < 7; ++u) { tapoff.push_back(u * 55 * 32); fidx.push_back(u); }
+    ok &= build_k_schedule(d, tapoff, fidx, 22 * 32, dtype);
+    d.s_tap = 16LL * 704; d.s_n = 704; d.s_c = 1;           // gtoep [u][n][x'*32 + c]
+  }
   if (!ok) { delete g; return set_err(RGP_EINVAL, "rgp_grcn_create: unsupported channel geometry P=%d S=%d", P, S); }
 
   Arena a;
-  for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3}) d->reserve(a, dtype);
+  for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3, &g->d3t}) d->reserve(a, dtype);
   for (ConvDesc& d : g->d1) d.reserve(a, dtype);
   for (ConvDesc& d : g->d2) d.reserve(a, dtype);
   g->tab_pad9_P = pad_tab(7, 1, P); g->o_pad9_P = put_tab(a, g->tab_pad9_P);
@@ -289,6 +314,8 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
   g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es);
   g->gfold = take(a, 50 * 32 * 4);
+  g->gtoep = take(a, (size_t)7 * 16 * 704 * 4);
+  g->bias16 = take(a, 16 * 4);
   g->frame_loss = take(a, (size_t)F * 4);
   if (g->save) {
     const int rc = grcn_bwd_plan(g, a);
@@ -317,7 +344,7 @@ int rgp_grcn_bind_workspace(rgp_grcn_t* g, void* workspace, size_t bytes, rgp_st
   // zero everything once: halos of E / Hp / RHp / Hbn / D1 / D2 stay zero because
   // epilogues only ever write interiors.
   RGP_HIP(hipMemsetAsync(g->ws, 0, g->ws_bytes, s));
-  for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3}) RGP_TRY(upload_desc(*d, g->ws, s));
+  for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3, &g->d3t}) RGP_TRY(upload_desc(*d, g->ws, s));
   for (ConvDesc& d : g->d1) RGP_TRY(upload_desc(d, g->ws, s));
   for (ConvDesc& d : g->d2) RGP_TRY(upload_desc(d, g->ws, s));
   auto up = [&](const std::vector<int>& t, size_t off) -> int {
