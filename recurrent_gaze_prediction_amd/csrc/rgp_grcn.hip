@@ -312,7 +312,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->rhp = take(a, (size_t)batch * 81 * S * es);
   g->hbn = take(a, (size_t)F * 81 * S * es);
   g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
-  g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es);
+  g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es + 4096);   // slack: the Toeplitz filter-gradient rows of pixel block 3 read past the last row
   g->gfold = take(a, 50 * 32 * 4);
   g->gtoep = take(a, (size_t)7 * 16 * 704 * 4);
   g->bias16 = take(a, 16 * 4);

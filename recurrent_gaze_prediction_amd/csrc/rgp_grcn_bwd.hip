@@ -26,7 +26,7 @@ struct GrcnBwd {
   size_t o_y = 0, o_pad3S = 0, o_pad2S = 0, o_koff_c = 0;
   long long M = 0, M2 = 0, Mp = 0, M2p = 0;
   Buf dz, frame_sum, dgp, gp, dd2, dd1, dy, dh_head, dh_carry, drh, dcp_pad, dzr_pad, dxpre, dxpre_pad, dE, rh_all;
-  Buf hp_all, rhp_all, sq_partial;     // halo-padded h_{t-1} and r.h_{t-1} of every step, [t][b][9][9][S] (wgrad operands)
+  Buf hp_all, rhp_all, dzb, ptoep, sq_partial;   // dzb / ptoep: blocked dz and the Toeplitz partial sums of the head filter gradient     // halo-padded h_{t-1} and r.h_{t-1} of every step, [t][b][9][9][S] (wgrad operands)
   rgp_grcn_weights w;   // forward weights (device fp32) as last set
 };
 
@@ -35,6 +35,28 @@ namespace {
 constexpr int SQ_BLOCKS = 256;
 
 size_t put(Arena& a, const std::vector<int>& t) { return a.take(t.size() * 4); }
+
+// Folded 7x7 head filter gradient dGp[u,v,c] = sum_{f,y,x} dz[f,y,x] d2pad[f,y+u,x+v,c] as seven wgrad_kernel launches
+// (the Toeplitz view of run_d3): rows = (frame, y, block of 16 x), X = the 16 dz values of the block, dY = the 704-element
+// run d2pad[y+u, 16xb .. +21, :]  ->  P[u][n][x'*32+c];  dGp[u,v,c] = sum_n P[u][n][(n+v)*32+c].
+// dz in blocks of 16 pixels: [f][y][xb 0..3][n]; block 3 starts at x = 48 and holds one pixel (the rest zero)
+template <typename T>
+__global__ __launch_bounds__(256) void dz_block_kernel(const float* __restrict__ dz, T* __restrict__ dzb, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i & 15), xb = (int)((i >> 4) & 3);
+    const long long fy = i >> 6;                               // f*49 + y
+    const int x = 16 * xb + n;
+    dzb[i] = Elem<T>::to(x < 49 ? dz[fy * 49 + x] : 0.f);
+  }
+}
+__global__ void head_fold_toeplitz_kernel(const float* __restrict__ P, float* __restrict__ dgp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // over 49 taps x 32 channels
+  if (i >= 49 * 32) return;
+  const int c = i % 32, v = (i / 32) % 7, u = i / (32 * 7);
+  float a = 0.f;
+  for (int n = 0; n < 16; ++n) a += P[((long long)u * 16 + n) * 704 + (n + v) * 32 + c];
+  dgp[i] = a;
+}
 
 // out[c] += sum over rows of x[r][c]; thread = (row lane, 8-column group), one atomic per column and block
 template <typename T>
@@ -91,7 +113,25 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   dlogits_kernel<<<F, 256, 0, s>>>(loss_l2 ? logits : probs, labels, Fp(b->dz), Fp(b->frame_sum), 2401, 1.0f / (float)F, loss_l2);
   sum_kernel<<<1, 256, 0, s>>>(Fp(b->frame_sum), (float*)gr->out_b, F, 1.0f);
   // 2. folded 7x7 filter: wgrad -> dF3, d out_W ; dgrad -> dd2
-  head_fold_wgrad_kernel<T><<<F, 256, 0, s>>>(Fp(b->dz), Tp(g->D2), Fp(b->dgp));
+  {
+    const long long tot = (long long)F * 49 * 64;
+    dz_block_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 4096), 256, 0, s>>>(Fp(b->dz), Tp(b->dzb), tot);
+    RGP_HIP(hipGetLastError());
+    RGP_HIP(hipMemsetAsync(ws + b->ptoep.off, 0, (size_t)7 * 16 * 704 * 4, s));
+    WgradParams p = wg_params();
+    p.X = Tp(b->dzb); p.dY = Tp(g->D2);
+    wgrad_grid(p, 1, 49, 4);
+    p.x_sx = 16; p.x_sy = 64; p.x_img_stride = 49LL * 64;
+    p.y_sx = 16 * 32; p.y_sy = 55 * 32; p.y_img_stride = 55LL * 55 * 32;
+    p.koff = I(b->o_koff_c); p.M = (long long)F * 196; p.N = 704; p.nk = 1; p.ldw = 704; p.k_valid = 16;
+    for (int u = 0; u < 7; ++u) {
+      p.y_org = u * 55 * 32;
+      p.dW = Fp(b->ptoep) + (size_t)u * 16 * 704;
+      RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    }
+    head_fold_toeplitz_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(Fp(b->ptoep), Fp(b->dgp));
+    RGP_HIP(hipGetLastError());
+  }
   head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
   head_fold_dgrad_kernel<T><<<dim3(49, F), 256, 0, s>>>(Fp(b->dz), Fp(b->gp), Tp(b->dd2));
   RGP_HIP(hipGetLastError());
@@ -321,6 +361,8 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   b->dxpre_pad = take(a, (size_t)F * 81 * 3 * S * es);
   b->dE = take(a, (size_t)(b->M + 1) * P * es);        // + a leading zero row
   b->rh_all = take(a, st * T_);
+  b->dzb = take(a, ((size_t)F * 49 * 64 + 256) * es);
+  b->ptoep = take(a, (size_t)7 * 16 * 704 * 4);
   b->hp_all = take(a, (size_t)T_ * B * 81 * S * es);
   b->rhp_all = take(a, (size_t)T_ * B * 81 * S * es);
   b->sq_partial = take(a, SQ_BLOCKS * 4);

@@ -173,6 +173,10 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
     for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fcol = lane & 15, g = lane >> 4;
+  // filter rows of this wave's K-chunk that exist: a wave whose chunk lies beyond nk, and 16-row tiles beyond
+  // k_valid (channel padding, or a 16-row problem such as the head's Toeplitz filter gradient), skip their MFMAs
+  const int my_rows = (kt * 4 + wk < p.nk) ? p.k_valid - (kt * 4 + wk) * BKE : 0;
+  const int ci_n = my_rows <= 0 ? 0 : (my_rows >= BKE ? CI : (my_rows + 15) >> 4);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto compute = [&](int buf) {
     const char* xb = smem + buf * S::STAGE + wk * 4096;
@@ -243,8 +247,10 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
       }
 #pragma unroll
       for (int i = 0; i < CI; ++i)
+        if (i < ci_n) {
 #pragma unroll
-        for (int j = 0; j < WNT; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
+          for (int j = 0; j < WNT; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
+        }
     } else {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -256,8 +262,10 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
         for (int j = 0; j < WNT; ++j) b[j] = *(const float*)(yb + row * YROW + ((wn * WNT + j) * 16 + fcol) * 4);
 #pragma unroll
         for (int i = 0; i < CI; ++i)
+          if (i < ci_n) {
 #pragma unroll
-          for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          }
       }
     }
   };
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
     if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
     if (!(p.ablate & 2)) issue((s + 2) % 3);
-    if (!(p.ablate & 1)) compute(s % 3);
+    if (!(p.ablate & 1) && ci_n > 0) compute(s % 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
