@@ -312,7 +312,9 @@ size_t rgp_c3d_param_offset(const rgp_c3d_t* plan, int layer, int is_bias);
 int rgp_c3d_backward(rgp_c3d_t* plan, const float* d_features, const float* d_rows, int n_windows, float* grads,
                      rgp_stream_t stream);
 /* After rgp_c3d_backward: the gradient w.r.t. layer i's conv output before ReLU/pooling (what dgrad and
- * wgrad of that layer consumed) as dense fp32 [n, D, H, W, Cout]. */
+ * wgrad of that layer consumed) as dense fp32 [n, D, H, W, Cout].  Valid until the next forward/backward of
+ * the plan.  (bf16 layer 0: the backward pass works from the pooled gradient and never builds this image; the
+ * call expands it on demand from the pooled gradient and arg-max codes the pass left behind.) */
 int rgp_c3d_read_grad_image(rgp_c3d_t* plan, int layer, int n_windows, float* dst, rgp_stream_t stream);
 
 /* Per-layer timing, as rgp_grcn_profile_*: index 0..7 = conv1a..conv5b (one fused

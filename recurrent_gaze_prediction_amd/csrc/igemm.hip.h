@@ -67,6 +67,7 @@ struct IgemmParams {
   int N;                     // real output channels
   int K;                     // packed K (multiple of BKE)
   int nk;                    // K / BKE
+  int ntile_group = 0;       // staggered kernel: row tiles per column-tile run (0 / 1 = column tiles innermost)
 };
 
 // Epilogue operands (superset; each functor reads what it needs).

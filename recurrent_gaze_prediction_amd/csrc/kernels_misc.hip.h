@@ -36,7 +36,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                           const int* __restrict__ tap_src, int ntaps, int cin_k,
                                                           int cin_src, int n_rows, int row0, int K, long long s_tap,
-                                                          long long s_n, long long s_c, int k0, int grouped, int row_step) {
+                                                          long long s_n, long long s_c, int k0, int grouped, int row_step,
+                                                          int chunk_major = 0) {
   const long long total = (long long)n_rows * ntaps * cin_k;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % cin_k);
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restric
     const int ts = tap_src ? tap_src[tap] : tap;
     float v = 0.f;
     if (ts >= 0 && c < cin_src) v = src[ts * s_tap + n * s_n + c * s_c];
-    dst[(long long)(row0 + n * row_step) * K + tap * cin_k + k0 + c] = Elem<T>::to(v);
+    // chunk_major = B: K index (channel chunk, tap, channel in chunk) instead of (tap, channel)
+    const int col = chunk_major ? (c / chunk_major) * (ntaps * chunk_major) + tap * chunk_major + (c % chunk_major) : tap * cin_k + k0 + c;
+    dst[(long long)(row0 + n * row_step) * K + col] = Elem<T>::to(v);
   }
 }
 

@@ -272,6 +272,9 @@ int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for
       }
       ok &= build_k_schedule(d, tapoff, fidx, C, dtype);
       d.s_tap = (long long)l.cin * l.cout; d.s_c = l.cout; d.s_n = 1;   // DHWIO
+      // RGP_KORDER=0 keeps the tap-major K order; the LDS-halo kernels (RGP_HALO) index the filter tap-major
+      static const bool cm = !getenv("RGP_HALO") && (getenv("RGP_KORDER") ? atoi(getenv("RGP_KORDER")) != 0 : true);
+      if (cm) make_chunk_major(d, dtype);
     }
     d.reserve(a, dtype);
     c->unpad_off[i] = a.take(c->unpad_tab[i].size() * 4);

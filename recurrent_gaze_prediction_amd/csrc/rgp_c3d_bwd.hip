@@ -151,7 +151,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         p.y_sx = l.cout; p.y_sy = Wp * l.cout; p.y_sz = Hp * Wp * l.cout;
         p.y_org = p.y_sz + p.y_sy + p.y_sx;
       }
-      p.koff = (const int*)(ws + c->L[i].koff_off);
+      p.koff = (const int*)(ws + c->L[i].koff_tm_off);      // tap-major: dW rows in DHWIO order
       p.x_img_stride = c->act_stride[i];
       p.y_img_stride = b.dypre_stride;
       p.M = (long long)n * Mw;
@@ -253,6 +253,8 @@ int c3d_bwd_plan(rgp_c3d* c, Arena& a) {
       }
       ok &= build_k_schedule(d, tapoff, fidx, Co, dtype);
       d.s_tap = (long long)l.cin * l.cout; d.s_n = l.cout; d.s_c = 1;    // W[tap][n = cin][c = cout]
+      static const bool cm = getenv("RGP_KORDER") ? atoi(getenv("RGP_KORDER")) != 0 : true;
+      if (cm) make_chunk_major(d, dtype);                               // same L2 argument as the forward convs
       if (pooled(i - 1)) {
         d.out_img_stride = (long long)d.Mw * l.cin;
         for (int m = 0; m < d.Mw; ++m) d.out_tab.push_back(m * l.cin);

@@ -19,6 +19,7 @@ int upload_desc(const ConvDesc& d, char* ws, hipStream_t s) {
   if (!d.in_tab.empty()) RGP_HIP(hipMemcpyAsync(ws + d.in_tab_off, d.in_tab.data(), d.in_tab.size() * 4, hipMemcpyHostToDevice, s));
   if (!d.out_tab.empty()) RGP_HIP(hipMemcpyAsync(ws + d.out_tab_off, d.out_tab.data(), d.out_tab.size() * 4, hipMemcpyHostToDevice, s));
   if (!d.koff.empty()) RGP_HIP(hipMemcpyAsync(ws + d.koff_off, d.koff.data(), d.koff.size() * 4, hipMemcpyHostToDevice, s));
+  if (!d.koff_tm.empty()) RGP_HIP(hipMemcpyAsync(ws + d.koff_tm_off, d.koff_tm.data(), d.koff_tm.size() * 4, hipMemcpyHostToDevice, s));
   if (!d.tap_src.empty()) RGP_HIP(hipMemcpyAsync(ws + d.tap_src_off, d.tap_src.data(), d.tap_src.size() * 4, hipMemcpyHostToDevice, s));
   return RGP_OK;
 }

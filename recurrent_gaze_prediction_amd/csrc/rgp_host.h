@@ -56,6 +56,11 @@ struct ConvDesc {
   int Mw = 0, N = 0, K = 0, nk = 0, G = 1, P = 1;
   long long in_img_stride = 0, out_img_stride = 0;
   std::vector<int> in_tab, out_tab, koff;
+  // chunk-major K order (make_chunk_major): koff / the packed filter run (channel chunk, tap) instead of (tap, channel
+  // chunk); koff_tm keeps the tap-major table (wgrad_kernel: its row order is the filter's own DHWIO order)
+  int chunk_major = 0;               // elements per chunk (BKE) when on
+  std::vector<int> koff_tm;
+  size_t koff_tm_off = 0;
   // filter packing: dst[n][tap*cin_k + c] = src[tap_src[tap]*s_tap + n*s_n + c*s_c]
   std::vector<int> tap_src;
   int pack_taps = 0, cin_k = 0, cin_src = 0;
@@ -68,6 +73,7 @@ struct ConvDesc {
     in_tab_off = a.take(in_tab.size() * 4);
     out_tab_off = a.take(out_tab.size() * 4);
     koff_off = a.take(koff.size() * 4);
+    koff_tm_off = koff_tm.empty() ? koff_off : a.take(koff_tm.size() * 4);
     tap_src_off = a.take(tap_src.size() * 4);
     w_off = a.take(w_bytes(dtype));
   }
@@ -108,6 +114,20 @@ inline bool build_k_schedule(ConvDesc& d, const std::vector<int>& tapoff, const 
   return true;
 }
 
+// Re-order the K schedule of a G == 1 problem from (tap, channel chunk) to (channel chunk, tap).  The im2col gather then
+// sweeps all taps of ONE 128-byte channel slice before moving to the next: the slice of a tile's input region
+// (a few hundred KB per XCD) stays in L2 across its 27 taps, where the tap-major order re-fetched the whole
+// multi-MB region per tap (conv3b / conv4a / conv4b read 9...17x their input from beyond L2).
+inline bool make_chunk_major(ConvDesc& d, int dtype) {
+  const int B = bke(dtype);
+  if (d.G != 1 || d.cin_k % B || d.cin_k / B < 2) return false;
+  const int nc = d.cin_k / B, nt = d.pack_taps;
+  d.koff_tm = d.koff;
+  for (int t = 0; t < nt; ++t) for (int c = 0; c < nc; ++c) d.koff[c * nt + t] = d.koff_tm[t * nc + c];
+  d.chunk_major = B;
+  return true;
+}
+
 int upload_desc(const ConvDesc& d, char* ws, hipStream_t s);
 
 template <typename T>
@@ -119,7 +139,7 @@ int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int r
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   pack_filter_kernel<T><<<blocks, 256, 0, s>>>(src, (T*)(ws + d.w_off), (const int*)(ws + d.tap_src_off), d.pack_taps,
                                                d.cin_k, d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_n, d.s_c, k0, grouped,
-                                               row_step);
+                                               row_step, d.chunk_major);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
@@ -161,7 +181,11 @@ int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
     if (n_cu <= 0) n_cu = 256;
   }
   const int tiles = n_mt * n_nt;
-  kern<<<dim3(persist ? std::min(tiles, n_cu) : tiles), dim3(512), smem, s>>>(p, e);
+  const int grid = persist ? std::min(tiles, n_cu) : tiles;
+  IgemmParams q = p;
+  static const int ngrp = getenv("RGP_NGROUP") ? atoi(getenv("RGP_NGROUP")) : 1;      // 1 = column tiles innermost (measured best); -1 = one XCD's worth of row tiles per column tile
+  q.ntile_group = ngrp >= 0 ? ngrp : std::max(1, std::min(grid, n_cu) / 8);
+  kern<<<dim3(grid), dim3(512), smem, s>>>(q, e);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
