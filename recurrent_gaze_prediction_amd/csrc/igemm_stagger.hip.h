@@ -340,6 +340,13 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       Bias::NoBias::apply_at(e, p.N, img, mlp, s_rowout[rt], n0 + cg * 8, v);
     }
   }
+  // Every load of this epilogue must be known-complete on EVERY path before the next K loop.  bias8 (and the mask of
+  // EpiStoreMask) is consumed only under `img >= 0`; on the other path it stays "maybe pending" in the compiler's
+  // register scoreboard, and the K loop then gets an `s_waitcnt vmcnt(0)` in front of whichever instruction re-uses
+  // one of those registers -- it was the fragment reads of the P = 1 kernels (conv3a / conv4a / conv5a / conv5b), i.e.
+  // the LDS-DMA ring was drained every K-tile.  The builtin is an s_waitcnt the compiler accounts for; what it waits
+  // for here (the item stores) the table commit below was waiting for anyway.  scripts/check_isa_waits.py lints this.
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
   stamp(7);                                        // seg[7] = everything after the K loop (epilogue)
   if (next_tile >= nwg) break;
   if (tid < BM) row_commit(set ^ 1, nxt);

@@ -1,0 +1,62 @@
+"""Dev lint: compile the conv translation units to gfx950 assembly and flag any s_waitcnt vmcnt(...) the compiler
+placed directly in front of a K-loop fragment-read cluster (>= 8 ds_read_b128) of an igemm_stagger_kernel.
+
+Why: the staggered kernel keeps two K-tiles of LDS-DMA in flight with counted waits of its own.  Whether the compiler
+adds a draining `s_waitcnt vmcnt(0)` before the fragment reads depends on its register scoreboard at the loop header
+(a global load consumed only under a condition leaves "maybe pending" registers; re-using one of them inside the loop
+forces the wait) -- it appeared and disappeared with unrelated edits during round 1.  Run after touching
+igemm_stagger.hip.h / igemm.hip.h epilogues:   python scripts/check_isa_waits.py
+"""
+import os, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'recurrent_gaze_prediction_amd', 'csrc')
+
+
+def kernels(asm):
+    lines = asm.split('\n')
+    for st, l in enumerate(lines):
+        if l.startswith('_ZN3rgp20igemm_stagger_kernel') and '@' in l:
+            end = next(i for i in range(st, len(lines)) if 's_endpgm' in lines[i])
+            yield l.split(':')[0], lines[st:end]
+
+
+def stray_waits(body):
+    i, bad = 0, []
+    while i < len(body):
+        if 'ds_read_b128' in body[i]:
+            j = i
+            while j < len(body) and ('ds_read_b128' in body[j] or 'v_add_u32' in body[j]):
+                j += 1
+            n = sum('ds_read_b128' in l for l in body[i:j])
+            pre = [l.strip() for l in body[max(0, i - 14):i] if 'vmcnt' in l]
+            if n >= 8 and pre:
+                bad.append((i, pre))
+            i = j
+        else:
+            i += 1
+    return bad
+
+
+def main():
+    rc = 0
+    for tu in ('rgp_c3d.hip', 'rgp_c3d_bwd.hip'):
+        with tempfile.NamedTemporaryFile(suffix='.s') as tf:
+            subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
+                            '-I' + CSRC, '-S', '--cuda-device-only', '-o', tf.name, os.path.join(CSRC, tu)], check=True,
+                           stderr=subprocess.DEVNULL)
+            asm = open(tf.name).read()
+        n = nbad = 0
+        for name, body in kernels(asm):
+            n += 1
+            bad = stray_waits(body)
+            if bad:
+                nbad += 1
+                print('STRAY WAIT', tu, name[:90], bad[:2])
+        print('%s: %d staggered kernels, %d with a compiler wait in front of the fragment reads' % (tu, n, nbad))
+        rc |= nbad > 0
+    sys.exit(rc)
+
+
+if __name__ == '__main__':
+    main()
