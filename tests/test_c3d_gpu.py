@@ -126,3 +126,23 @@ np.save(sys.argv[1], f.cpu().numpy())
         assert np.array_equal(outs[0], outs[1])
     else:
         assert rel_err(outs[1], outs[0]) < 2e-2
+
+
+def test_full_size_launch_chain_is_clip_independent(gpu):
+    """BASELINE size: 768 windows in ONE launch chain (every layer, conv5a/5b included, then runs the persistent
+    staggered kernel; below 669 windows conv5* take the 128x128 loop) built from 8 distinct windows repeated 96
+    times.  Each replica must reproduce, bit for bit, the features of the 8-window run: windows are independent,
+    and both kernels reduce K in the same order."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p = syn.c3d_params(21)
+    v8 = torch.tensor(syn.video_windows(23, 8), device=gpu)
+    small = C3DEngine(8, dtype='bf16', device=gpu)
+    small.set_weights(p)
+    f8 = small.forward(v8)[0].clone()
+    del small
+    big = C3DEngine(768, dtype='bf16', device=gpu)
+    big.set_weights(p)
+    f = big.forward(v8.repeat(96, 1, 1, 1, 1))[0]
+    assert torch.isfinite(f).all() and float(f.abs().max()) > 0
+    assert torch.equal(f.reshape(96, 8, -1), f8.reshape(1, 8, -1).expand(96, 8, f8[0].numel()))
