@@ -68,6 +68,7 @@ struct IgemmParams {
   int K;                     // packed K (multiple of BKE)
   int nk;                    // K / BKE
   int ntile_group = 0;       // staggered kernel: row tiles per column-tile run (0 / 1 = column tiles innermost)
+  int pool_regs = 1;         // staggered kernel, P = 8 without arg-max: pool in registers before staging (RGP_POOLREGS)
 };
 
 // Epilogue operands (superset; each functor reads what it needs).

@@ -313,14 +313,58 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias8[i] = (n0 + cg * 8 + i < p.N) ? e.bias[n0 + cg * 8 + i] : 0.f;
   }
+  // 2x2x2 pooling without arg-max: a lane holds 4 of a window's 8 rows (registers r = 0..3) and the lane 16 away
+  // the other 4, so the window maximum is one v_max3 + v_max in the lane and one ds_swizzle (lane ^ 16) -- the staged
+  // tile is the POOLED one, 32 x BN instead of 256 x BN floats: an eighth of the LDS traffic of the general path.
+  bool pooled_in_regs = false;
+  if constexpr (P == 8) pooled_in_regs = e.argmax == nullptr && (p.pool_regs & 1);
+  if (pooled_in_regs) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int jn = 0; jn < NI; ++jn)
+      for (int jn = 0; jn < NI; ++jn) {
+        const f32x4 c = acc[i][jn];
+        const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+        const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
+        if ((fk & 1) == 0) stg[(wm * (WTM / 8) + i * 2 + (fk >> 1)) * LDS_LD + wn * WTN + jn * 16 + frow] = fmaxf(x, y);
+      }
+  } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        stg[(wm * WTM + i * 16 + fk * 4 + r) * LDS_LD + wn * WTN + jn * 16 + frow] = acc[i][jn][r];
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stg[(wm * WTM + i * 16 + fk * 4 + r) * LDS_LD + wn * WTN + jn * 16 + frow] = acc[i][jn][r];
+  }
   __syncthreads();
+  // Every load of this epilogue (the look-ups, bias8) is made known-complete HERE, on every path and before any store
+  // is issued: (i) a load consumed only under a condition (bias8 under `img >= 0`) otherwise stays "maybe pending" in
+  // the compiler's register scoreboard, and the K loop then gets an `s_waitcnt vmcnt(0)` in front of whichever
+  // instruction re-uses one of those registers -- it was the fragment reads of the P = 1 kernels (conv3a / conv4a /
+  // conv5a / conv5b): the LDS-DMA ring was drained every K-tile (scripts/check_isa_waits.py lints this); (ii) placed
+  // after the stores the same wait would sit out their completion latency.  The builtin is an s_waitcnt the compiler
+  // accounts for.
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+  if (next_tile < nwg && tid < BM) row_commit(set ^ 1, nxt);
+  if (pooled_in_regs) {
+    {
+      const int rt = (tid / CG) * 8;                 // 512 threads = 32 pooled rows x 16 column groups
+      const int img = s_rowimg[rt];
+      if (img >= 0) {
+        float v[8];
+        const float* src = stg + (tid / CG) * LDS_LD + cg * 8;
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
+        if constexpr (Bias::value) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += bias8[i];
+        }
+        Bias::NoBias::apply_at(e, p.N, img, s_rowml[rt] / P, s_rowout[rt], n0 + cg * 8, v);
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
     const int it = tid + k * NT;
@@ -340,16 +384,9 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       Bias::NoBias::apply_at(e, p.N, img, mlp, s_rowout[rt], n0 + cg * 8, v);
     }
   }
-  // Every load of this epilogue must be known-complete on EVERY path before the next K loop.  bias8 (and the mask of
-  // EpiStoreMask) is consumed only under `img >= 0`; on the other path it stays "maybe pending" in the compiler's
-  // register scoreboard, and the K loop then gets an `s_waitcnt vmcnt(0)` in front of whichever instruction re-uses
-  // one of those registers -- it was the fragment reads of the P = 1 kernels (conv3a / conv4a / conv5a / conv5b), i.e.
-  // the LDS-DMA ring was drained every K-tile.  The builtin is an s_waitcnt the compiler accounts for; what it waits
-  // for here (the item stores) the table commit below was waiting for anyway.  scripts/check_isa_waits.py lints this.
-  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+  }
   stamp(7);                                        // seg[7] = everything after the K loop (epilogue)
   if (next_tile >= nwg) break;
-  if (tid < BM) row_commit(set ^ 1, nxt);
   __syncthreads();               // the fp32 tile has been read (the stage ring is free) and the next tables are in place
   if (ABLATE & 32) t_entry = t_prev;
   set ^= 1;

@@ -185,6 +185,8 @@ int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   IgemmParams q = p;
   static const int ngrp = getenv("RGP_NGROUP") ? atoi(getenv("RGP_NGROUP")) : 1;      // 1 = column tiles innermost (measured best); -1 = one XCD's worth of row tiles per column tile
   q.ntile_group = ngrp >= 0 ? ngrp : std::max(1, std::min(grid, n_cu) / 8);
+  static const int pool_regs = getenv("RGP_POOLREGS") ? atoi(getenv("RGP_POOLREGS")) : 1;
+  q.pool_regs = pool_regs;
   kern<<<dim3(grid), dim3(512), smem, s>>>(q, e);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
