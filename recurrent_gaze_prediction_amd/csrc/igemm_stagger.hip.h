@@ -205,6 +205,8 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
 
   stamp(-1);
   if (ABLATE & 32) seg[5] += t_start - t_entry;     // dev: prologue (replaces the bar2 column)
+  unsigned long long r_start = 0;                   // dev: 100 MHz wall clock around the K loop -> in-kernel shader clock
+  if (ABLATE & 32) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_start)::"memory");
   int st = 0;       // stage of K-tile j
 #pragma clang loop unroll(disable)
   for (int j = 0; j < p.nk; ++j) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    stamp(3);
+    stamp(2);                                      // (barrier wait folded into the "wait" column; slot 3 holds the wall clock)
     // ---------------- COMPUTE(j) ----------------
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -279,7 +281,12 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
     stamp(4);
     st = st + 1 == 3 ? 0 : st + 1;
   }
-  if (ABLATE & 32) seg[6] += t_prev - t_start;
+  if (ABLATE & 32) {
+    seg[6] += t_prev - t_start;
+    unsigned long long r_end;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_end)::"memory");
+    seg[3] += r_end - r_start;
+  }
   if (!group_b) __builtin_amdgcn_s_barrier();
   __syncthreads();
 

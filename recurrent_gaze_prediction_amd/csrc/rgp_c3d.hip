@@ -35,9 +35,9 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
     for (int b = 0; b < nblk; ++b) for (int w = 0; w < 8; ++w) for (int k = 0; k < 8; ++k)
       (w < 4 ? sumA : sumB)[k] += (double)h[((size_t)b * 8 + w) * 8 + k];
     const double n = (double)nblk * 4 * p.nk;
-    fprintf(stderr, "[stamp layer %d nk=%d] cycles per K-tile: group A dma %.0f reads %.0f wait %.0f bar1 %.0f mfma %.0f bar2 %.0f | group B dma %.0f reads %.0f wait %.0f bar1 %.0f mfma %.0f bar2 %.0f | loop total/ktile A %.0f | epilogue/loop A %.3f B %.3f | prologue cycles A %.0f B %.0f\n",
+    fprintf(stderr, "[stamp layer %d nk=%d] cycles per K-tile: group A dma %.0f reads %.0f wait %.0f bar1 %.0f mfma %.0f bar2 %.0f | group B dma %.0f reads %.0f wait %.0f bar1 %.0f mfma %.0f bar2 %.0f | loop total/ktile A %.0f | epilogue/loop A %.3f B %.3f | prologue cycles A %.0f B %.0f | in-kernel clock %.2f GHz (K loops: s_memtime / s_memrealtime x 100 MHz; the bar1 columns hold the wall ticks)\n",
             i, p.nk, sumA[0] / n, sumA[1] / n, sumA[2] / n, sumA[3] / n, sumA[4] / n, sumA[5] / n, sumB[0] / n, sumB[1] / n,
-            sumB[2] / n, sumB[3] / n, sumB[4] / n, sumB[5] / n, sumA[6] / n, sumA[7] / sumA[6], sumB[7] / sumB[6], sumA[5] / (nblk * 4.0), sumB[5] / (nblk * 4.0));
+            sumB[2] / n, sumB[3] / n, sumB[4] / n, sumB[5] / n, sumA[6] / n, sumA[7] / sumA[6], sumB[7] / sumB[6], sumA[5] / (nblk * 4.0), sumB[5] / (nblk * 4.0), sumA[6] / sumA[3] * 0.1);
     return rc;
   }
   return launch_igemm<T, G, P, EpiStore<T, true, true>>(p, e, s);

@@ -7,6 +7,6 @@ n = 256
 eng = C3DEngine(n, dtype='bf16')
 eng.set_weights(syn.c3d_params(1))
 v = torch.rand(n, 16, 112, 112, 3, device='cuda') - 0.5
-for _ in range(2):
+for _ in range(int(os.environ.get("RGP_STAMP_ITERS", "2"))):
     eng.forward(v, want_features=False)
 torch.cuda.synchronize()
