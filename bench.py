@@ -106,7 +106,11 @@ def cpu_baseline(args, budget_s):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(rdist.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     rank, local_rank, world = rdist.env_world()
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)

@@ -154,6 +154,33 @@ int rgp_adam_clip_step_dev(float* params, const float* grads, float* m, float* v
                            int n_partials, const float* lr_t_dev, float beta1, float beta2, float eps, float max_grad_norm,
                            float* grad_norm_out, rgp_stream_t stream);
 
+/* The other two optimizers of create_train_op (base.py:268-273), same clip-then-apply contract and the same
+ * `partials` (rgp_global_sqnorm of every flat buffer, concatenated) as rgp_adam_clip_step_ext:
+ *  rgp_momentum_clip_step : tf.train.MomentumOptimizer(lr, momentum=0.9)   accum = momentum*accum + g; var -= lr*accum
+ *  rgp_rmsprop_clip_step  : tf.train.RMSPropOptimizer(lr, decay=0.9, momentum=0.9, epsilon=1e-10)
+ *                           ms = decay*ms + (1-decay)*g^2; mom = momentum*mom + lr*g/sqrt(ms+eps); var -= mom
+ *                           (TF initialises the ms slot to ones, mom to zeros: the caller owns the slots). */
+int rgp_momentum_clip_step(float* params, const float* grads, float* accum, long long n, const float* partials, int n_partials,
+                           float lr, float momentum, float max_grad_norm, float* grad_norm_out, rgp_stream_t stream);
+int rgp_rmsprop_clip_step(float* params, const float* grads, float* ms, float* mom, long long n, const float* partials,
+                          int n_partials, float lr, float decay, float momentum, float eps, float max_grad_norm,
+                          float* grad_norm_out, rgp_stream_t stream);
+
+/* l2 loss (gaze_rnn.py:387-389, gaze_grcn_cascade.py:428-441): loss[0] = sum 0.5 (maps - labels)^2 / frames over
+ * n elements; workspace: RGP_SQNORM_PARTIALS floats (deterministic two-stage sum). */
+int rgp_l2_loss_fwd(const float* maps, const float* labels, long long n, int frames, float* workspace, float* loss,
+                    rgp_stream_t stream);
+
+/* Inverted dropout as an op (tf.nn.dropout: keep element i iff floor(keep_prob + u_i) = 1, kept values / keep_prob).
+ * rgp_dropout_mask draws the keep mask (1 byte per element, 0 / 1) on the device with Philox-4x32-10 keyed by `seed`;
+ * element i uses word i&3 of counter block offset + i/4, so the draw is independent of the launch geometry and a
+ * caller advances `offset` by ceil(n/4) per training step.  The mask is the caller's: the training forward of a plan
+ * with a dropout site reads it (rgp_fcgru_set_dropout, rgp_cascade_set_dropout) and the backward gates with the same
+ * bytes.  rgp_dropout_apply is the op on a dense fp32 vector, in place (also its own backward). */
+int rgp_dropout_mask(unsigned char* mask, long long n, float keep_prob, unsigned long long seed, unsigned long long offset,
+                     rgp_stream_t stream);
+int rgp_dropout_apply(float* x, const unsigned char* mask, long long n, float keep_prob, rgp_stream_t stream);
+
 /* Stage timing (HIP events recorded on the caller's stream around each stage launch
  * group; costs two hipEventRecord per stage).  Stages: 0 proj (incl. transpose),
  * 1 xconv, 2 convgru sequence, 3 head (transposed convs), 4 softmax.
@@ -193,6 +220,11 @@ int rgp_fcgru_create_ex(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_
 int rgp_fcgru_backward(rgp_fcgru_t* plan, const float* logits, const float* probs, const float* labels,
                        const rgp_fcgru_weights* grads, int loss_type, rgp_stream_t stream);
 
+/* Training-time dropout on the projected features c3d_embedded [B*T*49, 32] (gaze_rnn.py:302-303; single_step feeds
+ * keep 0.5 when training, :529).  mask: device bytes [B*T*49*32] from rgp_dropout_mask (or the caller's own draw), read
+ * by every following forward AND backward until changed; keep_prob = 1 or mask = NULL switches the site off
+ * (inference, the default). */
+int rgp_fcgru_set_dropout(rgp_fcgru_t* plan, float keep_prob, const unsigned char* mask);
 /* ------------------------------------------------------------------ frame-wise ShallowNet */
 typedef struct rgp_shallownet rgp_shallownet_t;
 
@@ -256,6 +288,9 @@ int rgp_cascade_forward(rgp_cascade_t* plan, const float* frame_images, const fl
 int rgp_cascade_create_ex(rgp_cascade_t** plan, int batch, int n_steps, int image_hw, int dtype, int save_for_backward);
 int rgp_cascade_backward(rgp_cascade_t* plan, const float* gazemaps, const float* gt_gazemap, const rgp_cascade_weights* grads,
                          float* d_rows, rgp_stream_t stream);
+/* Training-time dropout on fc1's ReLU output, before the maxout (gaze_grcn_cascade.py:401-402).  mask: device bytes
+ * [B*T, 4802] in the layer's own unit order (unit j and j + 2401 are maxout partners); keep_prob = 1 or NULL = off. */
+int rgp_cascade_set_dropout(rgp_cascade_t* plan, float keep_prob, const unsigned char* mask);
 /* Intermediates of the last forward as dense fp32 (net[...] keys of gaze_grcn_cascade.py):
  * "frm_sal" [B*T,49,49], "rcn_outputs" [B,T,7,7,256], "rcn_upsampled_outputs" [B*T,49,49,64],
  * "gaze_rcn_outputs" [B*T,49,49,3] (top-cell states). */
@@ -311,6 +346,11 @@ size_t rgp_c3d_param_elems(const rgp_c3d_t* plan);
 size_t rgp_c3d_param_offset(const rgp_c3d_t* plan, int layer, int is_bias);
 int rgp_c3d_backward(rgp_c3d_t* plan, const float* d_features, const float* d_rows, int n_windows, float* grads,
                      rgp_stream_t stream);
+/* Data-parallel fine-tune (gradient buckets launched as their wgrads complete, late layers first).
+ * rgp_c3d_backward records an event on its stream once layer i's slice of `grads` (w[i] then b[i], see
+ * rgp_c3d_param_offset) is final; rgp_c3d_wait_layer_grads makes `waiting_stream` wait for that event, so the
+ * host can issue the RCCL all-reduce of the slice there while the backward of layers i-1..0 is still running. */
+int rgp_c3d_wait_layer_grads(rgp_c3d_t* plan, int layer, rgp_stream_t waiting_stream);
 /* After rgp_c3d_backward: the gradient w.r.t. layer i's conv output before ReLU/pooling (what dgrad and
  * wgrad of that layer consumed) as dense fp32 [n, D, H, W, Cout].  Valid until the next forward/backward of
  * the plan.  (bf16 layer 0: the backward pass works from the pooled gradient and never builds this image; the

@@ -134,6 +134,65 @@ def adam_step_tf(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     return params, m, v
 
 
+def momentum_step_tf(params, grads, accum, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer(lr, momentum=0.9) (base.py:272-273): accum = momentum*accum + g; var -= lr*accum."""
+    for k in params:
+        accum[k] = momentum * accum[k] + grads[k]
+        params[k] = params[k] - lr * accum[k]
+    return params, accum
+
+
+def rmsprop_step_tf(params, grads, ms, mom, lr, decay=0.9, momentum=0.9, eps=1e-10):
+    """tf.train.RMSPropOptimizer(lr, momentum=0.9) (base.py:270-271), TF defaults decay 0.9, epsilon 1e-10;
+    slots start at ms = 1, mom = 0:  ms = decay*ms + (1-decay) g^2;  mom = momentum*mom + lr*g/sqrt(ms+eps);
+    var -= mom."""
+    for k in params:
+        g = grads[k]
+        ms[k] = decay * ms[k] + (1 - decay) * g * g
+        mom[k] = momentum * mom[k] + lr * g / torch.sqrt(ms[k] + eps)
+        params[k] = params[k] - mom[k]
+    return params, ms, mom
+
+
+# --------------------------------------------------------------------------- dropout
+def dropout(x, keep_prob, mask):
+    """tf.nn.dropout with the draw made explicit: x / keep_prob * mask (mask = floor(keep_prob + u) in {0,1})."""
+    return x / keep_prob * mask.to(x.dtype)
+
+
+def philox4x32_10(counter, key):
+    """Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the
+    generator behind TF's and cuRAND's stateless streams).  counter [..., 4], key [..., 2] uint32 -> [..., 4]."""
+    import numpy as np
+    c = np.array(counter, dtype=np.uint64) & 0xFFFFFFFF
+    k = np.array(key, dtype=np.uint64) & 0xFFFFFFFF
+    c = np.broadcast_to(c, np.broadcast_shapes(c.shape[:-1], k.shape[:-1]) + (4,)).copy()
+    k = np.broadcast_to(k, c.shape[:-1] + (2,)).copy()
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[..., 0]
+        p1 = 0xCD9E8D57 * c[..., 2]
+        n0 = ((p1 >> 32) ^ c[..., 1] ^ k[..., 0]) & 0xFFFFFFFF
+        n1 = p1 & 0xFFFFFFFF
+        n2 = ((p0 >> 32) ^ c[..., 3] ^ k[..., 1]) & 0xFFFFFFFF
+        n3 = p0 & 0xFFFFFFFF
+        c = np.stack([n0, n1, n2, n3], -1)
+        k = np.stack([(k[..., 0] + 0x9E3779B9) & 0xFFFFFFFF, (k[..., 1] + 0xBB67AE85) & 0xFFFFFFFF], -1)
+    return c.astype(np.uint32)
+
+
+def dropout_mask(n, keep_prob, seed, offset=0):
+    """The keep mask rgp_dropout_mask draws: element i = word i&3 of Philox block (offset + i//4) under key `seed`;
+    u = (word >> 8) / 2^24 (float32); keep = floor(keep_prob + u) >= 1 (tf.nn.dropout's rule)."""
+    import numpy as np
+    nb = (n + 3) // 4
+    ctr = np.uint64(offset) + np.arange(nb, dtype=np.uint64)
+    counter = np.stack([ctr & np.uint64(0xFFFFFFFF), ctr >> np.uint64(32), np.zeros_like(ctr), np.zeros_like(ctr)], -1)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    w = philox4x32_10(counter, key).reshape(-1)[:n]
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (np.floor(np.float32(keep_prob) + u) >= 1.0).astype(np.uint8)
+
+
 # --------------------------------------------------------------------------- fc-GRU (config 2)
 def tf_gru_cell(x, h, gate_kernel, gate_bias, cand_kernel, cand_bias):
     """TF-1.x rnn_cell.GRUCell.call: [r,u] = sigmoid([x,h] Wg + bg);
@@ -145,11 +204,15 @@ def tf_gru_cell(x, h, gate_kernel, gate_bias, cand_kernel, cand_bias):
     return u * h + (1 - u) * c
 
 
-def fcgru_forward(c3d_input, p, gh=49, gw=49):
-    """gaze_rnn.py:284-357 (the ShallowNet branch :256-275 does not reach the output)."""
+def fcgru_forward(c3d_input, p, gh=49, gw=49, keep_prob=1.0, drop_mask=None):
+    """gaze_rnn.py:284-357 (the ShallowNet branch :256-275 does not reach the output).
+    keep_prob < 1 with drop_mask [B*T*49, 32]: the training-time tf.nn.dropout on c3d_embedded (:302-303)."""
     b, t = c3d_input.shape[:2]
     xr = c3d_input.permute(0, 1, 3, 4, 2)
-    emb = (xr.reshape(-1, 1024) @ p['proj_c3d_W'] + p['proj_c3d_b']).reshape(b, t, -1)  # [B,T,7*7*32]
+    emb = xr.reshape(-1, 1024) @ p['proj_c3d_W'] + p['proj_c3d_b']                        # [(B*T*49), 32]
+    if drop_mask is not None and keep_prob < 1.0:
+        emb = dropout(emb, keep_prob, torch.as_tensor(drop_mask).reshape(emb.shape))
+    emb = emb.reshape(b, t, -1)                                                           # [B,T,7*7*32]
     n = p['proj_out_W'].shape[0]
     h = torch.zeros(b, n, dtype=c3d_input.dtype)
     outs = []
@@ -183,10 +246,11 @@ def shallownet_forward(images_nhwc, p):
 
 
 # --------------------------------------------------------------------------- cascade (config 5)
-def cascade_forward(frame_images, c3d_input, p, want_all=False):
+def cascade_forward(frame_images, c3d_input, p, want_all=False, keep_prob=1.0, drop_mask=None):
     """gaze_grcn_cascade.py:188-423 as intended (the top cell sees
     concat(upsampled bottom state, ShallowNet saliency), the commented block :370-377).
-    frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] -> gazemaps [B,T,49,49]."""
+    frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] -> gazemaps [B,T,49,49].
+    keep_prob < 1 with drop_mask [B,T,4802]: tf.nn.dropout on relu(fc1) before the maxout (:401-402)."""
     b, t = c3d_input.shape[:2]
     sal = shallownet_forward(frame_images.reshape((-1,) + tuple(frame_images.shape[2:])), p['ShallowNet'])
     sal = sal.reshape(b, t, 49, 49, 1)                                           # :235-244
@@ -203,6 +267,8 @@ def cascade_forward(frame_images, c3d_input, p, want_all=False):
         g = grcn_cell(torch.cat([up, sal[:, i]], -1), g, top)                    # :370-379
         x = g.reshape(b, -1)                                                     # :383
         x = torch.relu(x @ p['LastProjection/fc1_w'] + p['LastProjection/fc1_b'])
+        if drop_mask is not None and keep_prob < 1.0:
+            x = dropout(x, keep_prob, torch.as_tensor(drop_mask).reshape(b, t, 4802)[:, i])
         x = torch.maximum(x[:, :2401], x[:, 2401:])
         x = torch.relu(x @ p['LastProjection/fc2_w'] + p['LastProjection/fc2_b'])
         x = torch.maximum(x[:, :2401], x[:, 2401:])

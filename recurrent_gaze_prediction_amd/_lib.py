@@ -129,6 +129,17 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     'rgp_adam_clip_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, c_void_p,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
+    'rgp_momentum_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
+    'rgp_rmsprop_clip_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_int,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                      c_void_p, c_void_p]),
+    'rgp_l2_loss_fwd': (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    'rgp_dropout_mask': (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p]),
+    'rgp_dropout_apply': (c_int, [c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_float, c_void_p]),
+    'rgp_fcgru_set_dropout': (c_int, [c_void_p, ctypes.c_float, c_void_p]),
+    'rgp_cascade_set_dropout': (c_int, [c_void_p, ctypes.c_float, c_void_p]),
+    'rgp_c3d_wait_layer_grads': (c_int, [c_void_p, c_int, c_void_p]),
     'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
     'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),

@@ -102,6 +102,10 @@ struct EpiParams {
   // pooling window, [img][Mw/P][N] bytes; null = not recorded
   unsigned char* argmax;
   const void* mask;          // EpiStoreMask: forward output whose sign gates the gradient
+  // EpiReluMaxout: training-time dropout between the ReLU and the maxout (gaze_grcn_cascade.py:401-402):
+  // keep bytes [img][N] in the layer's natural unit order (null = off), kept values * drop_inv_keep
+  const unsigned char* drop_mask;
+  float drop_inv_keep;
 };
 
 // ---------------------------------------------------------------------------
@@ -192,7 +196,12 @@ template <typename TO> struct EpiReluMaxout {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (2 * i + 1 < nvalid) {
-        const float a = fmaxf(v[2 * i] + e.bias[n0 + 2 * i], 0.f), b = fmaxf(v[2 * i + 1] + e.bias[n0 + 2 * i + 1], 0.f);
+        float a = fmaxf(v[2 * i] + e.bias[n0 + 2 * i], 0.f), b = fmaxf(v[2 * i + 1] + e.bias[n0 + 2 * i + 1], 0.f);
+        if (e.drop_mask) {    // packed column 2j = unit j, 2j+1 = unit j + N/2
+          const unsigned char* dm = e.drop_mask + (long long)img * N + (n0 >> 1) + i;
+          a = dm[0] ? a * e.drop_inv_keep : 0.f;
+          b = dm[N >> 1] ? b * e.drop_inv_keep : 0.f;
+        }
         dst[i] = Elem<TO>::to(fmaxf(a, b));
         // training: which half carries the gradient (tf.maximum sends ties to the first operand), 0 = ReLU-gated
         if (e.argmax) e.argmax[(long long)img * (N >> 1) + (n0 >> 1) + i] = fmaxf(a, b) > 0.f ? (a >= b ? 1 : 2) : 0;

@@ -6,8 +6,6 @@
 
 #include "rgp_c3d_plan.h"
 #include "conv1a.hip.h"
-#include "conv3d_halo.hip.h"
-#include "conv3d_halo_stagger.hip.h"
 
 using namespace rgp;
 
@@ -20,7 +18,8 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
   e.bias = c->bias[i];
   if (c->save && P > 1) e.argmax = (unsigned char*)(c->ws + c->B[i].argmax_off);
   // dev diagnostics (RGP_ABLATE=32 RGP_STAMP=<layer>): phase stamps of the staggered kernel
-  static const int stamp_layer = getenv("RGP_STAMP") ? atoi(getenv("RGP_STAMP")) : -1;
+#ifdef RGP_DEV_KNOBS
+  const int stamp_layer = dev_knob("RGP_STAMP", -1);
   if (stamp_layer == i) {
     static unsigned long long* dbg = nullptr;
     const int nblk = (p.M + 255) / 256 * ((p.N + 127) / 128);
@@ -40,6 +39,7 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
             sumB[2] / n, sumB[3] / n, sumB[4] / n, sumB[5] / n, sumA[6] / n, sumA[7] / sumA[6], sumB[7] / sumB[6], sumA[5] / (nblk * 4.0), sumB[5] / (nblk * 4.0), sumA[6] / sumA[3] * 0.1);
     return rc;
   }
+#endif
   return launch_igemm<T, G, P, EpiStore<T, true, true>>(p, e, s);
 }
 
@@ -58,97 +58,8 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s) {
   return RGP_OK;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int P>
-int run_halo(rgp_c3d* c, int i, int n, hipStream_t s) {
-  const HaloDesc& h = c->halo[i];
-  const ConvDesc& d = c->L[i];
-  HaloParams p;
-  p.A = c->ws + c->act_off[i];
-  p.W = c->ws + d.w_off;
-  p.halo_goff = (const int*)(c->ws + h.goff_off);
-  p.row_hp = (const int*)(c->ws + h.row_hp_off);
-  p.tap_shift = (const int*)(c->ws + h.tap_shift_off);
-  p.in_img_stride = d.in_img_stride;
-  p.Cin = kLayers[i].cin; p.N = d.N; p.K = d.K;
-  p.nchunks = kLayers[i].cin / Elem<T>::BKE;
-  p.HP8 = h.HP8; p.n_img = n;
-  p.shift_y = h.BX + 2; p.shift_z = (h.BY + 2) * (h.BX + 2);
-  p.nbx = h.nbx; p.nby = h.nby; p.nbz = h.nbz;
-  p.box_in_x = h.box_in[0]; p.box_in_y = h.box_in[1]; p.box_in_z = h.box_in[2];
-  p.box_out_x = h.box_out[0]; p.box_out_y = h.box_out[1]; p.box_out_z = h.box_out[2];
-  EpiParams e = make_epi(d, c->ws + c->act_off[i + 1], c->ws);
-  e.out_tab = (const int*)(c->ws + h.out_tab_off);
-  e.bias = c->bias[i];
-  auto kern = conv3d_halo_kernel<T, BM, BN, WM, WN, P, EpiStore<T, true, true>>;
-  const int bufs = 1;       // the 3-stage filter ring leaves room for one resident halo chunk
-  const int smem = 3 * BN * 128 + bufs * h.HP8 * 128 + h.HP8 * 4 + 27 * 4;
-  static int attr_smem = 0;
-  if (smem > attr_smem) {
-    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_smem = smem;
-  }
-  const int grid = n * h.nbx * h.nby * h.nbz * (d.N / BN);
-  kern<<<grid, WM * WN * 64, smem, s>>>(p, e, bufs);
-  RGP_HIP(hipGetLastError());
-  return RGP_OK;
-}
-
-// halo-resident + staggered two-group schedule (conv3d_halo_stagger.hip.h)
-template <typename T, int BM, int BN, int WM, int WN, int NST, int P>
-int run_halo_stagger(rgp_c3d* c, int i, int n, hipStream_t s) {
-  const HaloDesc& h = c->halo[i];
-  const ConvDesc& d = c->L[i];
-  HaloParams p;
-  p.A = c->ws + c->act_off[i];
-  p.W = c->ws + d.w_off;
-  p.halo_goff = (const int*)(c->ws + h.goff_off);
-  p.row_hp = (const int*)(c->ws + h.row_hp_off);
-  p.tap_shift = (const int*)(c->ws + h.tap_shift_off);
-  p.in_img_stride = d.in_img_stride;
-  p.Cin = kLayers[i].cin; p.N = d.N; p.K = d.K;
-  p.nchunks = kLayers[i].cin / Elem<T>::BKE;
-  p.HP8 = h.HP8; p.n_img = n;
-  p.shift_y = h.BX + 2; p.shift_z = (h.BY + 2) * (h.BX + 2);
-  p.nbx = h.nbx; p.nby = h.nby; p.nbz = h.nbz;
-  p.box_in_x = h.box_in[0]; p.box_in_y = h.box_in[1]; p.box_in_z = h.box_in[2];
-  p.box_out_x = h.box_out[0]; p.box_out_y = h.box_out[1]; p.box_out_z = h.box_out[2];
-  EpiParams e = make_epi(d, c->ws + c->act_off[i + 1], c->ws);
-  e.out_tab = (const int*)(c->ws + h.out_tab_off);
-  e.bias = c->bias[i];
-  auto kern = conv3d_halo_stagger_kernel<T, BM, BN, WM, WN, NST, P, EpiStore<T, true, true>>;
-  const int smem = NST * BN * 128 + h.HP8 * 128;
-  if (h.HP8 > 640 || smem > 160 * 1024) return set_err(RGP_EINVAL, "halo-stagger kernel: LDS budget (layer %d)", i);
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
-  const int grid = n * h.nbx * h.nby * h.nbz * (d.N / BN);
-  kern<<<grid, 512, smem, s>>>(p, e);
-  RGP_HIP(hipGetLastError());
-  return RGP_OK;
-}
-
 template <typename T>
 int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
-  // LDS-halo direct kernel: correct but not faster than the staggered tile loop yet;
-  // opt-in while it is being tuned
-  static const int use_halo = getenv("RGP_HALO") ? atoi(getenv("RGP_HALO")) : 0;
-  // the halo kernel needs (2 filter stages + 1 or 2 halo buffers) <= 160 KiB of LDS;
-  // otherwise (fp32 conv2a: two 75 KiB halo chunks) the im2col tile loop runs instead
-  const int bn_ = i == 1 ? 128 : 256;
-  const bool fits = 3 * bn_ * 128 + c->halo[i].HP8 * 128 + c->halo[i].HP8 * 4 + 108 <= 160 * 1024;
-  // (training plans record the pooling arg-max, which only the im2col epilogues do)
-  if (use_halo == 2 && c->halo[i].used && !c->save) {
-    if (i == 1) return run_halo_stagger<T, 256, 128, 4, 2, 4, 8>(c, i, n, s);
-    if (i == 2) return run_halo_stagger<T, 128, 256, 2, 4, 3, 1>(c, i, n, s);
-    if (i == 3) return run_halo_stagger<T, 128, 256, 2, 4, 3, 8>(c, i, n, s);
-  }
-  if (use_halo == 1 && c->halo[i].used && fits && !c->save) {
-    if (i == 1) return run_halo<T, 256, 128, 4, 2, 8>(c, i, n, s);
-    if (i == 2) return run_halo<T, 128, 256, 2, 4, 1>(c, i, n, s);
-    if (i == 3) return run_halo<T, 128, 256, 2, 4, 8>(c, i, n, s);
-  }
   constexpr int G0 = sizeof(T) == 2 ? 4 : 2;
   if (i == 0 && sizeof(T) == 2) return run_conv1a_bf16(c, n, s);
   switch (i) {
@@ -272,35 +183,10 @@ int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for
       }
       ok &= build_k_schedule(d, tapoff, fidx, C, dtype);
       d.s_tap = (long long)l.cin * l.cout; d.s_c = l.cout; d.s_n = 1;   // DHWIO
-      // RGP_KORDER=0 keeps the tap-major K order; the LDS-halo kernels (RGP_HALO) index the filter tap-major
-      static const bool cm = !getenv("RGP_HALO") && (getenv("RGP_KORDER") ? atoi(getenv("RGP_KORDER")) != 0 : true);
-      if (cm) make_chunk_major(d, dtype);
+      if (dev_knob("RGP_KORDER", 1)) make_chunk_major(d, dtype);      // dev RGP_KORDER=0: tap-major K order
     }
     d.reserve(a, dtype);
     c->unpad_off[i] = a.take(c->unpad_tab[i].size() * 4);
-    if (i >= 1 && i <= 3) {   // conv2a / conv3a / conv3b: LDS-halo direct kernel
-      HaloDesc& h = c->halo[i];
-      h.used = true;
-      if (i == 1) { h.BZ = 4; h.BY = 8; h.BX = 8; } else { h.BZ = 8; h.BY = 4; h.BX = 4; }
-      const int HZ = h.BZ + 2, HY = h.BY + 2, HX = h.BX + 2, HPn = HZ * HY * HX;
-      h.HP8 = (HPn + 7) / 8 * 8;
-      h.nbx = W / h.BX; h.nby = H / h.BY; h.nbz = D / h.BZ;
-      h.goff.assign(h.HP8, 0);
-      for (int hz = 0; hz < HZ; ++hz) for (int hy = 0; hy < HY; ++hy) for (int hx = 0; hx < HX; ++hx)
-        h.goff[(hz * HY + hy) * HX + hx] = ((hz * Hp + hy) * Wp + hx) * C;
-      for (int zo = 0; zo < h.BZ / l.pd; ++zo) for (int yo = 0; yo < h.BY / l.ph; ++yo) for (int xo = 0; xo < h.BX / l.ph; ++xo) {
-        for (int dz = 0; dz < l.pd; ++dz) for (int dy = 0; dy < l.ph; ++dy) for (int dx = 0; dx < l.ph; ++dx)
-          h.row_hp.push_back(((zo * l.pd + dz) * HY + yo * l.ph + dy) * HX + xo * l.ph + dx);
-        h.out_tab.push_back((((zo + 1) * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * l.cout);
-      }
-      for (int kz = 0; kz < 3; ++kz) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
-        h.tap_shift.push_back((kz * HY + ky) * HX + kx);
-      h.box_in[0] = h.BX * C; h.box_in[1] = h.BY * Wp * C; h.box_in[2] = h.BZ * Hp * Wp * C;
-      h.box_out[0] = (h.BX / l.ph) * l.cout; h.box_out[1] = (h.BY / l.ph) * (Wo + 2) * l.cout;
-      h.box_out[2] = (h.BZ / l.pd) * (Ho + 2) * (Wo + 2) * l.cout;
-      h.goff_off = a.take(h.goff.size() * 4); h.row_hp_off = a.take(h.row_hp.size() * 4);
-      h.tap_shift_off = a.take(h.tap_shift.size() * 4); h.out_tab_off = a.take(h.out_tab.size() * 4);
-    }
   }
   c->act_stride[8] = 49LL * 1024;
   c->starts_off = a.take((size_t)max_windows * 4);
@@ -333,13 +219,6 @@ int rgp_c3d_bind_workspace(rgp_c3d_t* c, void* workspace, size_t bytes, rgp_stre
   for (int i = 0; i < 8; ++i) {
     RGP_TRY(upload_desc(c->L[i], c->ws, s));
     RGP_HIP(hipMemcpyAsync(c->ws + c->unpad_off[i], c->unpad_tab[i].data(), c->unpad_tab[i].size() * 4, hipMemcpyHostToDevice, s));
-    const HaloDesc& h = c->halo[i];
-    if (h.used) {
-      RGP_HIP(hipMemcpyAsync(c->ws + h.goff_off, h.goff.data(), h.goff.size() * 4, hipMemcpyHostToDevice, s));
-      RGP_HIP(hipMemcpyAsync(c->ws + h.row_hp_off, h.row_hp.data(), h.row_hp.size() * 4, hipMemcpyHostToDevice, s));
-      RGP_HIP(hipMemcpyAsync(c->ws + h.tap_shift_off, h.tap_shift.data(), h.tap_shift.size() * 4, hipMemcpyHostToDevice, s));
-      RGP_HIP(hipMemcpyAsync(c->ws + h.out_tab_off, h.out_tab.data(), h.out_tab.size() * 4, hipMemcpyHostToDevice, s));
-    }
   }
   if (c->save) RGP_TRY(c3d_bwd_upload(c, s));
   return RGP_OK;

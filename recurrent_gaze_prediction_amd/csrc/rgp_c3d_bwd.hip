@@ -171,11 +171,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         q.dw = grads + b.grad_w;
         q.db = grads + b.grad_b;
         q.n_windows = n;
-        static bool attr_done = false;
-        if (!attr_done) {
-          RGP_HIP(hipFuncSetAttribute((const void*)conv1a_wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W1_SMEM));
-          attr_done = true;
-        }
+        RGP_TRY(ensure_dyn_smem((const void*)conv1a_wgrad_bf16_kernel, W1_SMEM));
         conv1a_wgrad_bf16_kernel<<<256, 512, W1_SMEM, s>>>(q);
         RGP_HIP(hipGetLastError());
       } else if (i == 0) {
@@ -189,6 +185,8 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         RGP_TRY((launch_wgrad<T, 1>(p, s)));
       }
     }
+    // layer i's gradient slice (filter here; bias here or, pooled layers, in the un-pool of the step before) is queued
+    if (c->grad_ev_made) RGP_HIP(hipEventRecord(c->grad_ev[i], s));
     if (i == 0) break;
     // gradient w.r.t. the layer input = pooled (or plain) output of layer i-1
     const C3dBwdLayer& lo = c->B[i - 1];
@@ -253,7 +251,7 @@ int c3d_bwd_plan(rgp_c3d* c, Arena& a) {
       }
       ok &= build_k_schedule(d, tapoff, fidx, Co, dtype);
       d.s_tap = (long long)l.cin * l.cout; d.s_n = l.cout; d.s_c = 1;    // W[tap][n = cin][c = cout]
-      static const bool cm = getenv("RGP_KORDER") ? atoi(getenv("RGP_KORDER")) != 0 : true;
+      const bool cm = dev_knob("RGP_KORDER", 1) != 0;
       if (cm) make_chunk_major(d, dtype);                               // same L2 argument as the forward convs
       if (pooled(i - 1)) {
         d.out_img_stride = (long long)d.Mw * l.cin;
@@ -321,6 +319,13 @@ size_t rgp_c3d_param_offset(const rgp_c3d_t* c, int layer, int is_bias) {
   return off;
 }
 
+int rgp_c3d_wait_layer_grads(rgp_c3d_t* c, int layer, rgp_stream_t waiting_stream) {
+  RGP_REQUIRE(c && layer >= 0 && layer <= 7, "rgp_c3d_wait_layer_grads: bad arguments");
+  if (!c->save || !c->grad_ev_made) return set_err(RGP_ESTATE, "rgp_c3d_wait_layer_grads: no backward has run on this plan");
+  RGP_HIP(hipStreamWaitEvent((hipStream_t)waiting_stream, c->grad_ev[layer], 0));
+  return RGP_OK;
+}
+
 int rgp_c3d_read_grad_image(rgp_c3d_t* c, int layer, int n_windows, float* dst, rgp_stream_t stream) {
   RGP_REQUIRE(c && c->ws && c->save && dst && layer >= 0 && layer <= 7 && n_windows > 0 && n_windows <= c->max_windows,
               "rgp_c3d_read_grad_image: bad arguments");
@@ -361,6 +366,10 @@ int rgp_c3d_backward(rgp_c3d_t* c, const float* d_features, const float* d_rows,
     return set_err(RGP_ESTATE, "rgp_c3d_backward: n_windows %d != windows of the last forward chunk (%d); forward at most "
                    "max_windows windows, then call backward", n_windows, c->last_n);
   hipStream_t s = (hipStream_t)stream;
+  if (!c->grad_ev_made) {
+    for (int i = 0; i < 8; ++i) RGP_HIP(hipEventCreateWithFlags(&c->grad_ev[i], hipEventDisableTiming));
+    c->grad_ev_made = true;
+  }
   return c->dtype == RGP_BF16 ? backward_impl<bf16_t>(c, d_features, d_rows, grads, s)
                               : backward_impl<float>(c, d_features, d_rows, grads, s);
 }

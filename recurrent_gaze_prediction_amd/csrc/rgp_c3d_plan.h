@@ -14,16 +14,6 @@ static const C3dLayerSpec kLayers[8] = {
     {256, 512, 4, 14, 1, 1}, {512, 512, 4, 14, 2, 2}, {512, 512, 2, 7, 1, 1},  {512, 512, 2, 7, 1, 1},
 };
 
-// Box decomposition of one layer for conv3d_halo_kernel (tables live in the workspace).
-struct HaloDesc {
-  bool used = false;
-  int BZ = 0, BY = 0, BX = 0, HP8 = 0, nbx = 0, nby = 0, nbz = 0, bufs = 1;
-  int box_in[3] = {0, 0, 0}, box_out[3] = {0, 0, 0};
-  std::vector<int> goff, row_hp, tap_shift, out_tab;
-  size_t goff_off = 0, row_hp_off = 0, tap_shift_off = 0, out_tab_off = 0;
-  size_t smem = 0;
-};
-
 // Backward state of one layer (present when the plan was created with save_for_backward).
 struct C3dBwdLayer {
   rgp::ConvDesc dg;                 // dgrad implicit GEMM over dYpre with the rotated, in/out-swapped filter (layers 1..7)
@@ -39,7 +29,6 @@ struct C3dBwdLayer {
 
 struct rgp_c3d {
   int max_windows = 0, dtype = RGP_BF16;
-  HaloDesc halo[8];
   rgp::ConvDesc L[8];
   size_t act_off[9] = {0};       // act[i] = halo-padded input of layer i; act[8] = conv5b rows
   long long act_stride[9] = {0}; // elements per window
@@ -58,6 +47,13 @@ struct rgp_c3d {
   size_t dw1_off = 0;            // conv1a filter gradient in its packed K order, fp32
   size_t n_params = 0;           // 27 655 936 = sum of w[i] + b[i]
   int last_n = 0;                // windows of the last forward (what backward differentiates)
+  // recorded on the backward's stream once layer i's filter + bias gradient kernels are enqueued: lets the host
+  // start the all-reduce of that layer's slice on another stream while the earlier layers are still differentiating
+  hipEvent_t grad_ev[8] = {nullptr};
+  bool grad_ev_made = false;
+  ~rgp_c3d() {
+    if (grad_ev_made) for (int i = 0; i < 8; ++i) (void)hipEventDestroy(grad_ev[i]);
+  }
 };
 
 // rgp_c3d_bwd.hip

@@ -243,6 +243,7 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
     EpiParams e = make_epi(g->fc1, ws + g->mo1, ws);
     e.bias = (const float*)(ws + g->b1i);
     if (save) e.argmax = (unsigned char*)(ws + g->mask1);
+    if (g->drop_mask && g->drop_keep < 1.0f) { e.drop_mask = g->drop_mask; e.drop_inv_keep = 1.0f / g->drop_keep; }
     RGP_TRY((launch_igemm<T, 1, 1, EpiReluMaxout<T>>(p, e, s)));
   }
   {
@@ -258,6 +259,14 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
 }  // namespace
 
 extern "C" {
+
+int rgp_cascade_set_dropout(rgp_cascade_t* g, float keep_prob, const unsigned char* mask) {
+  RGP_REQUIRE(g, "rgp_cascade_set_dropout: null plan");
+  RGP_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "rgp_cascade_set_dropout: keep_prob %g not in (0, 1]", (double)keep_prob);
+  g->drop_mask = keep_prob < 1.f ? mask : nullptr;
+  g->drop_keep = g->drop_mask ? keep_prob : 1.0f;
+  return RGP_OK;
+}
 
 int rgp_cascade_create(rgp_cascade_t** plan, int batch, int n_steps, int image_hw, int dtype) {
   return rgp_cascade_create_ex(plan, batch, n_steps, image_hw, dtype, 0);

@@ -155,7 +155,8 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     EpiParams e = make_epi(g->b_fc2, Fp(g->dmo1), ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
   }
-  maxout_bwd_kernel<T><<<nblk((long long)F * 2401), 256, 0, s>>>(Fp(g->dmo1), g->K2, nullptr, 1.0f, (const unsigned char*)(ws + g->mask1),
+  // fc1's dropout (when on): the winning half of a live unit was kept, so its gradient is d out / keep
+  maxout_bwd_kernel<T><<<nblk((long long)F * 2401), 256, 0, s>>>(Fp(g->dmo1), g->K2, nullptr, 1.0f / g->drop_keep, (const unsigned char*)(ws + g->mask1),
                                                                  Tp(g->dz1), (long long)F * 2401);
   fc_bias_grad_kernel<T><<<(4802 + 255) / 256, 256, 0, s>>>(Tp(g->dz1), F, (float*)gr->fc1_b);
   RGP_HIP(hipGetLastError());

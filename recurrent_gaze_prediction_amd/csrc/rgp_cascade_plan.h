@@ -23,6 +23,9 @@ struct rgp_cascade {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool weights_set = false;
+  // training-time dropout on fc1 (gaze_grcn_cascade.py:401-402): caller-owned keep bytes [F][4802], null = off
+  const unsigned char* drop_mask = nullptr;
+  float drop_keep = 1.0f;
 
   // ---- training (save_for_backward) ----
   bool save = false;

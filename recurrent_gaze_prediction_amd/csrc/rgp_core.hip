@@ -1,7 +1,41 @@
 // librgp_hip.so: error reporting, device info, softmax / cross-entropy entry point.
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "rgp_host.h"
 
 namespace rgp {
+
+int ensure_dyn_smem(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  RGP_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kernel})) return RGP_OK;
+  RGP_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kernel});
+  return RGP_OK;
+}
+
+int device_cu_count(int* n_cu) {
+  static std::mutex mu;
+  static int cached[64] = {0};
+  int dev = 0;
+  RGP_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 0 || dev >= 64 || !cached[dev]) {
+    int n = 0;
+    RGP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    n = n / 8 * 8;
+    if (n <= 0) n = 256;
+    if (dev < 0 || dev >= 64) { *n_cu = n; return RGP_OK; }
+    cached[dev] = n;
+  }
+  *n_cu = cached[dev];
+  return RGP_OK;
+}
 
 thread_local char g_err[512] = "";
 

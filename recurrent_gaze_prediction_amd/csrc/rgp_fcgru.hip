@@ -28,6 +28,9 @@ struct rgp_fcgru {
   char* ws = nullptr;
   bool weights_set = false;
   const float *proj_b = nullptr, *out_b = nullptr;
+  // training-time dropout on c3d_embedded (gaze_rnn.py:302-303): caller-owned keep bytes [F*49*32], null = off
+  const unsigned char* drop_mask = nullptr;
+  float drop_keep = 1.0f;
   // ---- training ----
   bool save = false;
   size_t hall_t = 0, uall = 0, rall = 0, call = 0;   // fp32 [T(+1)][B][np]
@@ -40,6 +43,10 @@ struct rgp_fcgru {
   size_t dE = 0;                                      // T [F+1][Kx]   row 0 zero
   size_t dwx = 0, dwh = 0, dwc = 0;                   // fp32 [Kx][3np], [np][2np], [np][np]
 };
+
+namespace rgp {
+int dropout_apply(void* x, int dtype, const unsigned char* mask, long long rows, int cols, long long ld, float keep, hipStream_t s);
+}
 
 namespace {
 
@@ -115,6 +122,8 @@ int forward_impl(rgp_fcgru* g, const float* c3d_input, float* logits, float* pro
     e.bias = g->proj_b;
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, true, false>>(p, e, s)));
   }
+  // tf.nn.dropout on the projected features (training only); a frame's 49*32 values are one row of E
+  if (g->drop_mask) RGP_TRY(dropout_apply(ws + g->E, g->dtype, g->drop_mask, F, g->nx, g->Kx, g->drop_keep, s));
   {  // hoisted x-parts of both GRU kernels, biases folded in
     IgemmParams p = make_params(g->xg, ws + g->E, ws, F);
     EpiParams e = make_epi(g->xg, ws + g->xpre, ws);
@@ -344,6 +353,7 @@ int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const f
     EpiParams e = make_epi(g->b_x, Tp(g->dE) + Kx, ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
   }
+  if (g->drop_mask) RGP_TRY(dropout_apply(Tp(g->dE) + Kx, g->dtype, g->drop_mask, F, g->nx, Kx, g->drop_keep, s));
   {
     RGP_HIP(hipMemsetAsync((void*)gr->proj_c3d_W, 0, (size_t)1024 * g->Cp * 4, s));
     memset(&wp, 0, sizeof(wp));
@@ -374,6 +384,14 @@ __global__ void fc_fold_bias_kernel(const float* __restrict__ colsum, float* __r
 }  // namespace
 
 extern "C" {
+
+int rgp_fcgru_set_dropout(rgp_fcgru_t* g, float keep_prob, const unsigned char* mask) {
+  RGP_REQUIRE(g, "rgp_fcgru_set_dropout: null plan");
+  RGP_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "rgp_fcgru_set_dropout: keep_prob %g not in (0, 1]", (double)keep_prob);
+  g->drop_mask = keep_prob < 1.f ? mask : nullptr;
+  g->drop_keep = g->drop_mask ? keep_prob : 1.0f;
+  return RGP_OK;
+}
 
 int rgp_fcgru_create(rgp_fcgru_t** plan, int batch, int n_steps, int gazemap_h, int gazemap_w, int dtype) {
   return rgp_fcgru_create_ex(plan, batch, n_steps, gazemap_h, gazemap_w, dtype, 0);

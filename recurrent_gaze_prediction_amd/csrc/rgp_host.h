@@ -38,6 +38,20 @@ int set_err(int code, const char* fmt, ...);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Development switches (ablations, tile-order experiments: DESIGN.md section 4) exist only in a build made with
+// `make DEV=1`; the product library reads no environment variable and keeps no per-process tuning state.
+#ifdef RGP_DEV_KNOBS
+inline int dev_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int dev_knob(const char*, int dflt) { return dflt; }
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: cached per (device, kernel),
+// so plans created on several devices of one process each get it.  device_cu_count: CUs of the current device,
+// rounded down to a multiple of 8 (one slice per XCD).
+int ensure_dyn_smem(const void* kernel, int bytes);
+int device_cu_count(int* n_cu);
+
 struct Arena {
   size_t off = 0;
   size_t take(size_t bytes) {
@@ -149,11 +163,7 @@ template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
 int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
   auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi>;
   constexpr int smem = IgemmSmem<BM, BN>::BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
   const int n_mt = (p.M + BM - 1) / BM, n_nt = (p.N + BN - 1) / BN;
   kern<<<dim3(n_mt * n_nt, ksplit), dim3(WM * WN * 64), smem, s>>>(p, e);
   RGP_HIP(hipGetLastError());
@@ -164,29 +174,18 @@ template <typename T, int P, class Epi, int ABLATE = 0>
 int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   auto kern = igemm_stagger_kernel<T, P, Epi, ABLATE>;
   constexpr int smem = StaggerSmem::BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
   const int n_mt = (p.M + 255) / 256, n_nt = (p.N + 127) / 128;
-  // persistent: one block per CU walks the tile list (RGP_PERSIST=0: one block per tile, dev comparison)
-  static const int persist = getenv("RGP_PERSIST") ? atoi(getenv("RGP_PERSIST")) : 1;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    RGP_HIP(hipGetDevice(&dev));
-    RGP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = n_cu / 8 * 8;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  // persistent: one block per CU walks the tile list (dev RGP_PERSIST=0: one block per tile)
+  const int persist = dev_knob("RGP_PERSIST", 1);
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
   const int tiles = n_mt * n_nt;
   const int grid = persist ? std::min(tiles, n_cu) : tiles;
   IgemmParams q = p;
-  static const int ngrp = getenv("RGP_NGROUP") ? atoi(getenv("RGP_NGROUP")) : 1;      // 1 = column tiles innermost (measured best); -1 = one XCD's worth of row tiles per column tile
+  const int ngrp = dev_knob("RGP_NGROUP", 1);      // 1 = column tiles innermost (measured best); -1 = one XCD's worth of row tiles per column tile
   q.ntile_group = ngrp >= 0 ? ngrp : std::max(1, std::min(grid, n_cu) / 8);
-  static const int pool_regs = getenv("RGP_POOLREGS") ? atoi(getenv("RGP_POOLREGS")) : 1;
-  q.pool_regs = pool_regs;
+  q.pool_regs = dev_knob("RGP_POOLREGS", 1);
   kern<<<dim3(grid), dim3(512), smem, s>>>(q, e);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
@@ -199,10 +198,11 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
   if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
   // 2 = staggered 256x128 kernel where eligible (default, fastest measured), 0 = 128x128 only,
   // 1 = 256x128 simple loop (dev comparison)
-  static const int tile_cfg = getenv("RGP_TILE") ? atoi(getenv("RGP_TILE")) : 2;
+  const int tile_cfg = dev_knob("RGP_TILE", 2);
   if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
   {
-    static const int abl = getenv("RGP_ABLATE") ? atoi(getenv("RGP_ABLATE")) : 0;
+#ifdef RGP_DEV_KNOBS
+    const int abl = dev_knob("RGP_ABLATE", 0);
     if constexpr (sizeof(T) == 2 && (P == 1 || P == 4)) { if (abl == 32) return launch_stagger<T, P, Epi, 32>(p, e, s); }
     if (sizeof(T) == 2 && P == 8 && abl) {
       if (abl == 1) return launch_stagger<T, P, Epi, 1>(p, e, s);
@@ -214,6 +214,7 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
       if (abl == 32) return launch_stagger<T, P, Epi, 32>(p, e, s);
       if (abl == 128) return launch_stagger<T, P, Epi, 128>(p, e, s);
     }
+#endif
     return launch_stagger<T, P, Epi>(p, e, s);
   }
   if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);

@@ -13,21 +13,16 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
   auto kern = wgrad_kernel<T, G, WNT>;
   constexpr int smem = WgradSmem<T, WNT>::BYTES;
   constexpr int BN = 32 * WNT;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RGP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
   if (p.M <= 0 || p.nk <= 0 || p.N <= 0) return set_err(RGP_EINVAL, "wgrad: empty problem");
   const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + BN - 1) / BN;
   const long long total_steps = (p.M + 31) / 32;
   // row ranges (splits): enough for ~1000 blocks (RGP_WGK_BLOCKS overrides), at least 8
-  static const int target = getenv("RGP_WGK_BLOCKS") ? atoi(getenv("RGP_WGK_BLOCKS")) : 1024;
+  const int target = dev_knob("RGP_WGK_BLOCKS", 1024);
   long long splits = std::max<long long>(8, target / (n_kt * n_nt));
   splits = std::min(splits, total_steps);
   WgradParams q = p;
-  static const int ablate = getenv("RGP_WG_ABLATE") ? atoi(getenv("RGP_WG_ABLATE")) : 0;
-  q.ablate = ablate;
+  q.ablate = dev_knob("RGP_WG_ABLATE", 0);
   q.steps_per_split = (int)((total_steps + splits - 1) / splits);
   splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
   kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
@@ -41,7 +36,7 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
 template <typename T, int G>
 int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    static const int wide = getenv("RGP_WG_WIDE") ? atoi(getenv("RGP_WG_WIDE")) : 1;
+    const int wide = dev_knob("RGP_WG_WIDE", 1);
     const int narrow_tiles = ((p.nk + 3) / 4) * ((p.N + 127) / 128);
     if (wide && p.N % 256 == 0 && (wide == 2 || narrow_tiles <= 64)) return launch_wgrad_t<T, G, 8>(p, s);
   }

@@ -140,6 +140,12 @@ class DeviceFeeder(object):
         else:
             slot = self.slots[self.n_staged % self.depth]
             assert slot['pin'].shape == host.shape, 'batches must share one shape'
+            h = slot.get('handle')
+            if h is not None and h._slot is not None:
+                # the consumer still holds this batch un-released: its kernels may not even be queued yet, so the
+                # event recorded at hand-over does not cover them -- drain the consumer's stream before re-filling
+                h._stream.synchronize()
+                h.release()
             if slot['free'] is not None:
                 slot['free'].synchronize()               # the pinned source is also being re-used
         self.n_staged += 1
@@ -166,7 +172,9 @@ class DeviceFeeder(object):
         cur = self.torch.cuda.current_stream(self.device)
         cur.wait_event(ready)
         slot['free'] = self.torch.cuda.Event()
-        return _Handed(slot['dev'], slot, cur)
+        slot['free'].record(cur)             # never an un-recorded event: release() re-records it later on
+        slot['handle'] = _Handed(slot['dev'], slot, cur)
+        return slot['handle']
 
 
 class _Handed(object):

@@ -41,10 +41,44 @@ def _as_dev_f32(x, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-def adam_clip_step_multi(engines, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8):
-    """tf.clip_by_global_norm over the gradients of ALL engines (base.py:286-292) + TF Adam on each engine's flat
-    buffers, then repack.  engines: objects with flat_params / flat_grads (GrcnEngine, C3DEngine).
-    Returns a 1-element device tensor with the pre-clip global norm."""
+OPTIMIZERS = ('adam', 'rmsprop', 'sgd')      # create_train_op (base.py:268-273)
+
+
+def _opt_slots(e, method):
+    """Optimizer slot buffers of one engine, created on first use with TF's initial values."""
+    if method == 'adam':
+        if getattr(e, 'adam_m', None) is None:
+            e.adam_m, e.adam_v = torch.zeros_like(e.flat_params), torch.zeros_like(e.flat_params)
+    elif method == 'rmsprop':
+        if getattr(e, 'rms_ms', None) is None:       # RMSPropOptimizer: rms slot starts at ones, momentum at zeros
+            e.rms_ms, e.rms_mom = torch.ones_like(e.flat_params), torch.zeros_like(e.flat_params)
+    elif method == 'sgd':
+        if getattr(e, 'mom_accum', None) is None:
+            e.mom_accum = torch.zeros_like(e.flat_params)
+    else:
+        raise ValueError('Invalid optimization method!')          # base.py:274
+
+
+OPT_STATE_KEYS = ('adam_m', 'adam_v', 'rms_ms', 'rms_mom', 'mom_accum')
+
+
+def optimizer_state(engine):
+    """{slot name: cpu tensor} of the slots that exist (what tf.train.Saver(tf.all_variables()) also saves,
+    base.py:236-251: a resumed run must not restart Adam's moments at zero)."""
+    return {k: getattr(engine, k).detach().cpu().clone() for k in OPT_STATE_KEYS if getattr(engine, k, None) is not None}
+
+
+def load_optimizer_state(engine, state):
+    for k, v in (state or {}).items():
+        if k in OPT_STATE_KEYS:
+            setattr(engine, k, torch.as_tensor(v).to(engine.device, torch.float32).contiguous().clone())
+
+
+def clip_step_multi(engines, step, lr, max_grad_norm=10.0, method='adam', beta1=0.9, beta2=0.999, eps=1e-8,
+                    momentum=0.9, rms_decay=0.9, rms_eps=1e-10):
+    """tf.clip_by_global_norm over the gradients of ALL engines (base.py:286-292) + the chosen optimizer
+    (base.py:268-273; TF defaults) on each engine's flat buffers, then repack.
+    engines: objects with flat_params / flat_grads.  Returns a 1-element device tensor with the pre-clip norm."""
     lib, dev = engines[0].lib, engines[0].device
     npart = _lib.RGP_SQNORM_PARTIALS
     partials = torch.zeros(npart * len(engines), dtype=torch.float32, device=dev)
@@ -54,14 +88,73 @@ def adam_clip_step_multi(engines, step, lr, max_grad_norm=10.0, beta1=0.9, beta2
             _lib.check(lib.rgp_global_sqnorm(_ptr(e.flat_grads), e.flat_grads.numel(), _ptr(partials[i * npart:]),
                                              _stream_ptr(dev)))
         for e in engines:
-            if getattr(e, 'adam_m', None) is None:
-                e.adam_m, e.adam_v = torch.zeros_like(e.flat_params), torch.zeros_like(e.flat_params)
-            _lib.check(lib.rgp_adam_clip_step_ext(_ptr(e.flat_params), _ptr(e.flat_grads), _ptr(e.adam_m), _ptr(e.adam_v),
-                                                  e.flat_params.numel(), _ptr(partials), partials.numel(), int(step),
-                                                  float(lr), beta1, beta2, eps, float(max_grad_norm), _ptr(gnorm),
-                                                  _stream_ptr(dev)))
+            _opt_slots(e, method)
+            n = e.flat_params.numel()
+            if method == 'adam':
+                _lib.check(lib.rgp_adam_clip_step_ext(_ptr(e.flat_params), _ptr(e.flat_grads), _ptr(e.adam_m), _ptr(e.adam_v),
+                                                      n, _ptr(partials), partials.numel(), int(step), float(lr), beta1,
+                                                      beta2, eps, float(max_grad_norm), _ptr(gnorm), _stream_ptr(dev)))
+            elif method == 'rmsprop':
+                _lib.check(lib.rgp_rmsprop_clip_step(_ptr(e.flat_params), _ptr(e.flat_grads), _ptr(e.rms_ms), _ptr(e.rms_mom),
+                                                     n, _ptr(partials), partials.numel(), float(lr), rms_decay, momentum,
+                                                     rms_eps, float(max_grad_norm), _ptr(gnorm), _stream_ptr(dev)))
+            else:
+                _lib.check(lib.rgp_momentum_clip_step(_ptr(e.flat_params), _ptr(e.flat_grads), _ptr(e.mom_accum), n,
+                                                      _ptr(partials), partials.numel(), float(lr), momentum,
+                                                      float(max_grad_norm), _ptr(gnorm), _stream_ptr(dev)))
             e.repack()
     return gnorm
+
+
+def adam_clip_step_multi(engines, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    return clip_step_multi(engines, step, lr, max_grad_norm, 'adam', beta1, beta2, eps)
+
+
+def l2_loss(maps, labels, frames):
+    """sum 0.5 (maps - labels)^2 / frames (gaze_rnn.py:387-389) -> 1-element device tensor."""
+    lib = _lib.load()
+    assert maps.is_cuda and maps.dtype == torch.float32 and maps.is_contiguous()
+    assert labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous() and labels.numel() == maps.numel()
+    ws = torch.empty(_lib.RGP_SQNORM_PARTIALS, dtype=torch.float32, device=maps.device)
+    loss = torch.empty(1, dtype=torch.float32, device=maps.device)
+    with torch.cuda.device(maps.device):
+        _lib.check(lib.rgp_l2_loss_fwd(_ptr(maps), _ptr(labels), maps.numel(), int(frames), _ptr(ws), _ptr(loss),
+                                       _stream_ptr(maps.device)))
+    return loss
+
+
+class DropoutSite(object):
+    """Keep-mask owner of one tf.nn.dropout site: draws a fresh Philox mask per training step on the device
+    (rgp_dropout_mask), or takes the caller's bytes (parity tests feed the oracle the same mask)."""
+
+    def __init__(self, lib, device, n_elems, setter):
+        self.lib, self.device, self.n, self._set = lib, device, int(n_elems), setter
+        self.mask = torch.ones(self.n, dtype=torch.uint8, device=device)
+        self.keep_prob, self.seed, self.draws = 1.0, 0, 0
+
+    def configure(self, keep_prob, seed=0):
+        self.keep_prob, self.seed, self.draws = float(keep_prob), int(seed), 0
+
+    def off(self):
+        _lib.check(self._set(ctypes.c_float(1.0), None))
+
+    def draw(self):
+        """New mask for this step (counter offset advances by ceil(n/4) blocks per draw)."""
+        if self.keep_prob >= 1.0:
+            return self.off()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_dropout_mask(_ptr(self.mask), self.n, self.keep_prob, self.seed,
+                                                 self.draws * ((self.n + 3) // 4), _stream_ptr(self.device)))
+        self.draws += 1
+        _lib.check(self._set(ctypes.c_float(self.keep_prob), _ptr(self.mask)))
+
+    def use(self, mask, keep_prob):
+        """Fixed mask (uint8 / bool array of n elements, reference order)."""
+        m = torch.as_tensor(np.asarray(mask).astype(np.uint8) if not torch.is_tensor(mask) else mask)
+        assert m.numel() == self.n, (m.numel(), self.n)
+        self.mask.copy_(m.reshape(-1).to(self.device, torch.uint8))
+        self.keep_prob = float(keep_prob)
+        _lib.check(self._set(ctypes.c_float(self.keep_prob), _ptr(self.mask)))
 
 
 class GrcnEngine(object):
@@ -143,12 +236,16 @@ class GrcnEngine(object):
             _lib.check(self.lib.rgp_grcn_backward_input(self._h, _ptr(d), _stream_ptr(self.device)))
         return d
 
-    def adam_step(self, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    def adam_step(self, step, lr, max_grad_norm=10.0, beta1=0.9, beta2=0.999, eps=1e-8, method='adam'):
         """clip_by_global_norm + TF AdamOptimizer on the flat buffers (base.py:286-297), then repack.
-        Returns a 1-element device tensor holding the pre-clip global gradient norm."""
-        if getattr(self, 'adam_m', None) is None:
-            self.adam_m = torch.zeros_like(self.flat_params)
-            self.adam_v = torch.zeros_like(self.flat_params)
+        Returns a 1-element device tensor holding the pre-clip global gradient norm.
+        method 'rmsprop' / 'sgd': the other two optimizers of base.py:268-273."""
+        if method != 'adam':
+            return clip_step_multi([self], step, lr, max_grad_norm, method)
+        if getattr(self, 'adam_m', None) is None or getattr(self, '_opt_ws', None) is None:
+            if getattr(self, 'adam_m', None) is None:       # (slots restored from a checkpoint are kept)
+                self.adam_m = torch.zeros_like(self.flat_params)
+                self.adam_v = torch.zeros_like(self.flat_params)
             self._opt_ws = torch.zeros(256, dtype=torch.float32, device=self.device)
             self._gnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
@@ -241,6 +338,9 @@ class FcGruEngine(object):
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_fcgru_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
         self.weights = None
+        # tf.nn.dropout on c3d_embedded [B*T*49, 32] (gaze_rnn.py:302-303): off until a training step draws a mask
+        self.dropout = DropoutSite(self.lib, self.device, self.B * self.T * 49 * 32,
+                                   lambda keep, mask: self.lib.rgp_fcgru_set_dropout(self._h, keep, mask))
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -289,13 +389,21 @@ class FcGruEngine(object):
                                                    {'xentropy': 0, 'l2': 1}[loss_type], _stream_ptr(self.device)))
         return self.grads
 
-    def adam_step(self, step, lr, max_grad_norm=10.0):
-        return adam_clip_step_multi([self], step, lr, max_grad_norm)
+    def adam_step(self, step, lr, max_grad_norm=10.0, method='adam'):
+        return clip_step_multi([self], step, lr, max_grad_norm, method)
 
-    def forward(self, c3d_input, want_probs=True):
+    def forward(self, c3d_input, want_probs=True, train=False):
+        """train=True draws a fresh dropout mask when dropout.configure(keep < 1) was called (single_step feeds
+        keep 0.5 in training, gaze_rnn.py:529); train=False runs with the site off, as every evaluation does."""
         x = c3d_input
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         assert tuple(x.shape) == (self.B, self.T, 1024, 7, 7), tuple(x.shape)
+        if train == 'keep':
+            pass                                   # a mask installed by dropout.use() stays as it is
+        elif train:
+            self.dropout.draw()
+        else:
+            self.dropout.off()
         logits = torch.empty(self.B, self.T, self.GH, self.GW, device=self.device)
         probs = torch.empty_like(logits) if want_probs else None
         with torch.cuda.device(self.device):
@@ -369,8 +477,8 @@ class ShallowNetEngine(object):
             _lib.check(self.lib.rgp_shallownet_backward(self._h, d.shape[0], _ptr(d), ctypes.byref(st), _stream_ptr(self.device)))
         return self.grads
 
-    def adam_step(self, step, lr, max_grad_norm=10.0):
-        return adam_clip_step_multi([self], step, lr, max_grad_norm)
+    def adam_step(self, step, lr, max_grad_norm=10.0, method='adam'):
+        return clip_step_multi([self], step, lr, max_grad_norm, method)
 
     def forward(self, frames, want_7x7=False):
         """frames [n,H,W,3] fp32 device tensor -> (saliency [n,49,49], saliency7 [n,7,7] or None)."""
@@ -415,6 +523,9 @@ class CascadeEngine(object):
             _lib.check(self.lib.rgp_cascade_bind_workspace(self._h, _ptr(self.workspace), nbytes,
                                                            _stream_ptr(self.device)))
         self.weights = None
+        # tf.nn.dropout on relu(fc1) [B*T, 4802] before the maxout (gaze_grcn_cascade.py:401-402)
+        self.dropout = DropoutSite(self.lib, self.device, self.batch * self.n_steps * 4802,
+                                   lambda keep, mask: self.lib.rgp_cascade_set_dropout(self._h, keep, mask))
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -469,9 +580,16 @@ class CascadeEngine(object):
                                                      _stream_ptr(self.device)))
         return self.grads, d_rows
 
-    def forward(self, frame_images, c3d_input):
-        """frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] fp32 device tensors -> maps [B,T,49,49]."""
+    def forward(self, frame_images, c3d_input, train=False):
+        """frame_images [B,T,H,W,3], c3d_input [B,T,1024,7,7] fp32 device tensors -> maps [B,T,49,49].
+        train: True = draw a dropout mask (if configured), 'keep' = leave an installed mask, False = site off."""
         B, T = self.batch, self.n_steps
+        if train == 'keep':
+            pass
+        elif train:
+            self.dropout.draw()
+        else:
+            self.dropout.off()
         assert frame_images.is_cuda and frame_images.dtype == torch.float32 and frame_images.is_contiguous()
         assert c3d_input.is_cuda and c3d_input.dtype == torch.float32 and c3d_input.is_contiguous()
         assert tuple(frame_images.shape) == (B, T, self.image_hw, self.image_hw, 3), tuple(frame_images.shape)
@@ -581,6 +699,16 @@ class C3DEngine(object):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_c3d_forward(self._h, _ptr(video), n, _ptr(feats), _ptr(rows), _stream_ptr(self.device)))
         return feats, rows
+
+    def layer_grad_slice(self, layer):
+        """View of flat_grads holding layer's filter then bias gradient (contiguous: one all-reduce bucket)."""
+        cin, cout = C3D_CHANNELS[layer]
+        ow = self.lib.rgp_c3d_param_offset(self._h, layer, 0)
+        return self.flat_grads[ow:ow + 27 * cin * cout + cout]
+
+    def wait_layer_grads(self, layer, stream):
+        """Make `stream` (a torch.cuda.Stream) wait until the last backward() has finished layer's gradient slice."""
+        _lib.check(self.lib.rgp_c3d_wait_layer_grads(self._h, int(layer), ctypes.c_void_p(stream.cuda_stream)))
 
     def read_grad_image(self, layer, n_windows):
         """After backward(): d loss / d (conv output of `layer` before ReLU and pooling), [n,D,H,W,Cout] fp32."""

@@ -18,6 +18,22 @@ from . import synthetic
 from .engine import C3DEngine, GrcnEngine, adam_clip_step_multi
 
 
+def _c3d_backward_chunks(m, video, d_rows, reducer):
+    """Conv-stack backward over the plan's window chunks; with a reducer, layer i's gradient bucket is handed to
+    RCCL as soon as the LAST chunk's layer-i kernels are queued (conv5b first), so the all-reduce of 110.6 MB runs
+    under the backward of the layers below instead of after it."""
+    chunks = m._chunks()
+    m.c3d.flat_grads.zero_()
+    for ci, (w0, n) in enumerate(chunks):
+        if len(chunks) > 1:          # recompute this chunk's activations (only the last chunk's are resident)
+            m.c3d.forward(video[w0:w0 + n], want_features=False)
+        m.c3d.backward(d_rows=d_rows[w0 * 49:(w0 + n) * 49], zero_grads=False)
+    if reducer is not None and reducer.dist is not None:
+        for layer in range(7, -1, -1):
+            reducer.reduce(m.c3d.layer_grad_slice(layer),
+                           ready=(lambda st, layer=layer: m.c3d.wait_layer_grads(layer, st)) if reducer.cuda else None)
+
+
 class EndToEndGaze(object):
     def __init__(self, batch, n_steps, dtype='bf16', device='cuda:0', max_windows=None, seed=0, c3d_params=None,
                  grcn_params=None, loss_type='xentropy'):
@@ -39,6 +55,7 @@ class EndToEndGaze(object):
 
     def attach_process_group(self, dist):
         self.dist = dist
+        self.reducer = rdist.GradBucketReducer(dist, self.device)
 
     def _chunks(self):
         m = self.c3d.max_windows
@@ -53,27 +70,25 @@ class EndToEndGaze(object):
 
     def backward(self, video, logits, probs, labels):
         """Fills both engines' flat_grads; returns the loss (device scalar)."""
-        from .engine import softmax_xent
+        from .engine import l2_loss, softmax_xent
         labels = labels.reshape(self.B, self.T, 49, 49).contiguous()
         if self.loss_type == 'xentropy':
             loss = softmax_xent(logits, labels, want_probs=False)[2]
         else:
-            loss = 0.5 * ((logits - labels) ** 2).sum() / float(self.F)
+            loss = l2_loss(logits, labels, self.F)
         self.head.backward(logits, probs, labels, self.loss_type)
+        red = getattr(self, 'reducer', None)
+        if red is not None:
+            red.reduce(self.head.flat_grads)          # 12 MB over xGMI while the conv stack differentiates
         self.head.backward_input(self.d_rows)
-        chunks = self._chunks()
-        self.c3d.flat_grads.zero_()
-        for w0, n in chunks:
-            if len(chunks) > 1:          # recompute this chunk's activations (only the last chunk's are resident)
-                self.c3d.forward(video[w0:w0 + n], want_features=False)
-            self.c3d.backward(d_rows=self.d_rows[w0 * 49:(w0 + n) * 49], zero_grads=False)
+        _c3d_backward_chunks(self, video, self.d_rows, red)
         return loss
 
     def train_step(self, video, labels, lr, max_grad_norm=10.0):
         logits, probs = self.forward(video, want_probs=self.loss_type == 'xentropy')
         loss = self.backward(video, logits, probs, labels)
-        if self.dist is not None:
-            rdist.allreduce_mean_(self.dist, [self.head.flat_grads, self.c3d.flat_grads])
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.finish()                     # every bucket reduced (mean) before the global-norm clip
         gnorm = adam_clip_step_multi(self.engines, self.global_step, lr, max_grad_norm)
         self.global_step += 1
         return loss, gnorm
@@ -107,6 +122,7 @@ class EndToEndCascade(object):
 
     def attach_process_group(self, dist):
         self.dist = dist
+        self.reducer = rdist.GradBucketReducer(dist, self.device)
 
     def _chunks(self):
         m = self.c3d.max_windows
@@ -119,22 +135,21 @@ class EndToEndCascade(object):
         return self.head.forward(frames, self.feats.reshape(self.B, self.T, 1024, 7, 7))
 
     def backward(self, video, maps, labels):
+        from .engine import l2_loss
         labels = labels.reshape(maps.shape).contiguous()
-        loss = 0.5 * ((maps - labels) ** 2).sum() / float(self.F)
+        loss = l2_loss(maps, labels, self.F)
         _, d_rows = self.head.backward(maps, labels, want_d_rows=True)
-        chunks = self._chunks()
-        self.c3d.flat_grads.zero_()
-        for w0, n in chunks:
-            if len(chunks) > 1:
-                self.c3d.forward(video[w0:w0 + n], want_features=False)
-            self.c3d.backward(d_rows=d_rows[w0 * 49:(w0 + n) * 49], zero_grads=False)
+        red = getattr(self, 'reducer', None)
+        if red is not None:
+            red.reduce(self.head.flat_grads)          # 216 MB: the largest bucket starts first
+        _c3d_backward_chunks(self, video, d_rows, red)
         return loss
 
     def train_step(self, video, frames, labels, lr, max_grad_norm=10.0):
         maps = self.forward(video, frames)
         loss = self.backward(video, maps, labels)
-        if self.dist is not None:
-            rdist.allreduce_mean_(self.dist, [self.head.flat_grads, self.c3d.flat_grads])
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.finish()
         gnorm = adam_clip_step_multi(self.engines, self.global_step, lr, max_grad_norm)
         self.global_step += 1
         return loss, gnorm

@@ -108,7 +108,17 @@ class ModelBase(object):
         checkpoint_dir = os.path.join(checkpoint_dir, "model")
         os.makedirs(checkpoint_dir, exist_ok=True)
         path = os.path.join(checkpoint_dir, '%s-%d.pt' % (model_name, self.current_step))
-        torch.save({'variables': self.state_dict(), 'global_step': self.current_step}, path)
+        # tf.train.Saver(tf.all_variables()) (base.py:240-251) also holds the optimizer slots (Adam m / v, beta
+        # powers = global_step here) -- without them a resumed run restarts the moments at zero with t ~ 1
+        # (first updates ~ lr * sign(g)); the learning-rate scale and the augmentation stream ride along.
+        from ..engine import optimizer_state
+        ck = {'variables': self.state_dict(), 'global_step': self.current_step,
+              'optimizer': [optimizer_state(e) for e in self._optimizer_engines()],
+              'learning_rate_scale': self._learning_rate_scale}
+        if getattr(self, 'flip_rng', None) is not None:
+            ck['flip_seed'] = getattr(self, 'flip_seed', None)
+            ck['flip_rng_state'] = self.flip_rng.get_state()
+        torch.save(ck, path)
         with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
             f.write(os.path.basename(path) + '\n')
         log.info(" [Checkpoint] Saved checkpoints into %s !", path)
@@ -118,6 +128,13 @@ class ModelBase(object):
         ck = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
         self.load_state_dict(ck['variables'])
         self._global_step = int(ck.get('global_step', 0))
+        self._learning_rate_scale = float(ck.get('learning_rate_scale', self._learning_rate_scale))
+        from ..engine import load_optimizer_state
+        for e, st in zip(self._optimizer_engines(), ck.get('optimizer', [])):
+            load_optimizer_state(e, st)
+        if ck.get('flip_rng_state') is not None and getattr(self, 'flip_rng', None) is not None:
+            self.flip_rng.set_state(ck['flip_rng_state'])
+            self.flip_seed = ck.get('flip_seed', getattr(self, 'flip_seed', None))
         log.info(" [Checkpoint] Successfully loaded from %s", checkpoint_path)
 
     def load_model_checkpoint(self, checkpoint_dir):
@@ -137,6 +154,12 @@ class ModelBase(object):
             return True
         log.error(" [Checkpoint] Failed to load model !! (starting from scratch)")
         return False
+
+    def _optimizer_engines(self):
+        """Device engines that own optimizer slots (flat_params + adam_m / ...)."""
+        e = getattr(self, 'engine', None)
+        e = getattr(e, 'net', e)
+        return [e] if e is not None and hasattr(e, 'flat_params') else []
 
     # ---- training loop (base.py:330-358) ---------------------------------------------
     def fit(self):

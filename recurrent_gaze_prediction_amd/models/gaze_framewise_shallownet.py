@@ -55,8 +55,8 @@ class _FramewiseEngine(object):
             d = d.reshape(F, 7, 1, 7, 1).expand(F, 7, 7, 7, 7).reshape(F, 49, 49) / 49.0
         return self.net.backward(d.reshape(F, 49, 49).contiguous())
 
-    def adam_step(self, step, lr, max_grad_norm=10.0):
-        return self.net.adam_step(step, lr, max_grad_norm)
+    def adam_step(self, step, lr, max_grad_norm=10.0, method='adam'):
+        return self.net.adam_step(step, lr, max_grad_norm, method=method)
 
     def forward(self, c3d, want_probs=False):
         m = self.model
@@ -92,6 +92,6 @@ class FramewiseShallowNet(GazePredictionGRU):
             net['variables'] = model.variables
         return engine
 
-    def predict(self, c3d, frames=None):
+    def predict(self, c3d, frames=None, train=False):
         self.engine.frames = frames
-        return super(FramewiseShallowNet, self).predict(c3d, frames)
+        return super(FramewiseShallowNet, self).predict(c3d, frames, train=train)

@@ -81,17 +81,17 @@ class _CascadeAdapter(object):
         assert loss_type == 'l2', 'the cascade is trained with the l2 loss (gaze_grcn_cascade.py:428-441)'
         return self.net.backward(logits, labels.reshape(logits.shape).contiguous())[0]
 
-    def adam_step(self, step, lr, max_grad_norm=10.0):
-        from ..engine import adam_clip_step_multi
-        return adam_clip_step_multi([self.net], step, lr, max_grad_norm)
+    def adam_step(self, step, lr, max_grad_norm=10.0, method='adam'):
+        from ..engine import clip_step_multi
+        return clip_step_multi([self.net], step, lr, max_grad_norm, method)
 
-    def forward(self, c3d, want_probs=False):
+    def forward(self, c3d, want_probs=False, train=False):
         m = self.model
         assert self.frames is not None, 'the cascade needs frame_images (predict(c3d, frames))'
         x = self.frames if torch.is_tensor(self.frames) else torch.as_tensor(np.asarray(self.frames, np.float32))
         x = x.to(m.session.device, torch.float32).reshape(m.batch_size, m.n_lstm_steps, self.net.image_hw,
                                                           self.net.image_hw, 3).contiguous()
-        maps = self.net.forward(x, c3d)
+        maps = self.net.forward(x, c3d, train=train)     # train: fc1's dropout draws a mask (gaze_grcn_cascade.py:401-402)
         probs = None
         if want_probs:
             from ..engine import softmax_xent
@@ -116,6 +116,8 @@ class GazePredictionGRCN(GazePredictionGRU):
         engine = _CascadeAdapter(model)
         model.variables = synthetic.cascade_params(getattr(model.config, 'init_seed', 0), engine.net.image_hw)
         engine.set_weights(model.variables)
+        engine.net.dropout.configure(getattr(model.config, 'train_keep_prob', 0.5),
+                                     seed=(getattr(model.config, 'init_seed', 0) << 20) + 0x2545f491)
         if net is not None:
             net['variables'] = model.variables
         return engine
@@ -135,6 +137,6 @@ class GazePredictionGRCN(GazePredictionGRU):
         self.variables = v
         self.engine.set_weights(v)
 
-    def predict(self, c3d, frames=None):
+    def predict(self, c3d, frames=None, train=False):
         self.engine.frames = frames
-        return super(GazePredictionGRCN, self).predict(c3d, frames)
+        return super(GazePredictionGRCN, self).predict(c3d, frames, train=train)

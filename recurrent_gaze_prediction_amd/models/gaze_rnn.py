@@ -2,9 +2,9 @@
 GazePredictionGRU harness (build_model / single_step / generate / evaluate).
 
 The harness is model-agnostic exactly as in the reference: subclasses supply
-``create_gazeprediction_network``; the gaze_grcn subclass runs on the HIP path.  The
-fc-GRU graph of this base class (gaze_rnn.py:211-360, BASELINE config 2) has no HIP
-path yet and says so when asked to build."""
+``create_gazeprediction_network``.  The fc-GRU graph of this base class (gaze_rnn.py:211-360,
+BASELINE config 2) runs forward AND backward on the HIP path (rgp_fcgru_*), including the
+training-time dropout on its projected features."""
 import logging
 import time
 from types import SimpleNamespace
@@ -36,9 +36,11 @@ class GRUModelConfig(BaseModelConfig):
         self.optimization_method = 'adam'
         self.loss_type = 'xentropy'
         self.use_flip_batch = True
-        # additions (not in the reference): MFMA operand dtype of the HIP path, weight seed
+        # additions (not in the reference): MFMA operand dtype of the HIP path, weight seed, augmentation seed
         self.compute_dtype = 'bf16'
         self.init_seed = 0
+        self.flip_seed = None          # None: derived from init_seed and the rank (recorded in the log / checkpoint)
+        self.train_keep_prob = 0.5     # keep_prob single_step feeds when training (gaze_rnn.py:529)
 
 
 class GazePredictionGRU(ModelBase):
@@ -62,6 +64,15 @@ class GazePredictionGRU(ModelBase):
         self.gazemap_height, self.gazemap_width = gazemap_height, gazemap_width
         self.image_height, self.image_width = CONSTANTS.image_height, CONSTANTS.image_width
         self.dropout_keep_prob = 1.0
+        # The reference's flip augmentation draws from numpy's GLOBAL RNG (gaze_rnn.py:504-510).  Data-parallel ranks
+        # must not mirror the same clips, and a run must be repeatable: each rank owns a seeded stream, seed recorded.
+        from .. import dist as rdist
+        rank = rdist.env_world()[0]
+        cfg_seed = getattr(self.config, 'flip_seed', None)
+        self.flip_seed = int(cfg_seed) if cfg_seed is not None else \
+            (int(getattr(self.config, 'init_seed', 0)) * 1000003 + 7919 * rank + 12345) & 0x7fffffff
+        self.flip_rng = np.random.RandomState(self.flip_seed)
+        log.info('flip-augmentation RNG: rank %d seed %d', rank, self.flip_seed)
         self.build_model()
         self.build_train_op()
 
@@ -79,9 +90,10 @@ class GazePredictionGRU(ModelBase):
     @staticmethod
     def create_gazeprediction_network(frame_images, c3d_input, dropout_keep_prob=1.0, net=None, model=None):
         """gaze_rnn.py:211-360: 1024->32 projection, GRUCell(7*7*32+49), linear read-out, on the HIP
-        path (rgp_fcgru_*).  The ShallowNet branch the reference also builds (:256-275) does not reach
-        the output and is not evaluated.  Dropout on the projected features (keep 0.5 in training,
-        SURVEY 9-Q2) is not applied: this class is inference-only here."""
+        path (rgp_fcgru_*), forward and backward.  The ShallowNet branch the reference also builds (:256-275)
+        does not reach the output and is not evaluated.  tf.nn.dropout on the projected features (:302-303)
+        is an op of the engine: off at inference, keep = config.train_keep_prob (0.5, :529) with a fresh
+        device-drawn mask per training step."""
         from .. import synthetic
         from ..engine import FcGruEngine
         assert model is not None
@@ -93,6 +105,8 @@ class GazePredictionGRU(ModelBase):
         model.variables = synthetic.fcgru_params(getattr(model.config, 'init_seed', 0), model.gazemap_height,
                                                  model.gazemap_width)
         engine.set_weights(model.variables)
+        engine.dropout.configure(getattr(model.config, 'train_keep_prob', 0.5),
+                                 seed=(getattr(model.config, 'init_seed', 0) << 20) + 0x5bd1e995)
         net['variables'] = model.variables
         return engine
 
@@ -106,27 +120,52 @@ class GazePredictionGRU(ModelBase):
         self.variables = {k: np.asarray(v, np.float32) for k, v in state.items()}
         self.engine.set_weights(self.variables)
 
+    def initialize_pretrained_shallownet(self, checkpoint_path):
+        """gaze_rnn.py:412-433: copy the ``ShallowNet/*`` variables of a separately trained checkpoint into this
+        model (optimizer slots and tflearn's is_training flags skipped).  checkpoint_path: an exported ``.npz`` of
+        {TF variable name: array} (checkpoint.load_tf_export)."""
+        from .. import checkpoint
+        shallow = checkpoint.import_shallownet_variables(checkpoint.load_tf_export(checkpoint_path))
+        state = self.state_dict()
+        if any(k.startswith('ShallowNet/') for k in state):          # cascade: nested sub-network
+            state.update({'ShallowNet/' + k: v for k, v in shallow.items()})
+        elif all(k in state for k in shallow):                        # frame-wise ShallowNet: the whole model
+            state.update(shallow)
+        else:
+            raise KeyError('%s has no ShallowNet variables' % type(self).__name__)
+        self.load_state_dict(state)
+        for k, v in shallow.items():
+            log.info('Using pretrained value for ShallowNet/%s : %s', k, str(v.shape))
+
     def build_train_op(self):
-        """(training is implemented for the gaze_grcn engine; other engines run inference only)
-        gaze_rnn.py:448-478 + base.py:262-308: gradients of the loss w.r.t. every non-ShallowNet
-        variable, clip_by_global_norm(max_grad_norm), AdamOptimizer(lr schedule).  Here: the engine's
-        backward + fused Adam kernels; with WORLD_SIZE > 1 the flat gradient bucket is all-reduced
-        (mean) over RCCL before the clip, so the clip sees the global-batch gradient."""
-        assert self.config.optimization_method == 'adam', 'only the reference default (adam) has a HIP kernel'
+        """gaze_rnn.py:448-478 + base.py:262-308: gradients of the loss w.r.t. every non-ShallowNet
+        variable, clip_by_global_norm(max_grad_norm), then the configured optimizer (adam / rmsprop / sgd with
+        momentum 0.9, base.py:268-273) at the scheduled learning rate.  Here: the engine's backward + the fused
+        clip+optimizer kernels; with WORLD_SIZE > 1 the flat gradient bucket is all-reduced (mean) over RCCL
+        before the clip, so the clip sees the global-batch gradient."""
+        from ..engine import OPTIMIZERS
+        if self.config.optimization_method not in OPTIMIZERS:
+            raise ValueError('Invalid optimization method!')          # base.py:274
         self.dist = None           # set by attach_process_group()
+        self.reducer = None
         self.train_op = self._train_op
 
     def attach_process_group(self, dist):
         """dist: torch.distributed (already initialised, backend nccl = RCCL) or None."""
+        from .. import dist as rdist
         self.dist = dist
+        self.reducer = rdist.GradBucketReducer(dist, self.session.device) if dist is not None else None
 
     def _train_op(self, logits, probs, labels_dev):
-        from .. import dist as rdist
         self.engine.backward(logits, probs, labels_dev, 'l2' if self.config.loss_type == 'l2' else 'xentropy')
-        if self.dist is not None:
-            rdist.allreduce_mean_(self.dist, [self.engine.flat_grads])
+        if self.reducer is not None:
+            self.reducer.reduce(self.engine.flat_grads)       # in place, fp32, mean over ranks
+            self.reducer.finish()
+        step_kw = {}
+        if self.config.optimization_method != 'adam':
+            step_kw['method'] = self.config.optimization_method
         self.grad_norm = self.engine.adam_step(self._global_step, self.learning_rate_at(self._global_step),
-                                               max_grad_norm=self.max_grad_norm)
+                                               max_grad_norm=self.max_grad_norm, **step_kw)
         self._global_step += 1
 
     def learning_rate_at(self, step):
@@ -138,27 +177,34 @@ class GazePredictionGRU(ModelBase):
         return self.learning_rate_at(self.current_step)
 
     # ------------------------------------------------------------------ execution
-    def predict(self, c3d, frames=None):
+    def predict(self, c3d, frames=None, train=False):
         """Replacement for ``session.run(predicted_gazemaps, feed_dict)`` (gaze_rnn.py:603-611):
         c3d [B,T,1024,7,7] (numpy or device tensor; frames are accepted and ignored)
-        -> numpy [B,T,GH,GW]: softmax maps for loss_type xentropy/KLD, raw maps for l2 (9-Q5)."""
+        -> numpy [B,T,GH,GW]: softmax maps for loss_type xentropy/KLD, raw maps for l2 (9-Q5).
+        train=True is single_step's training feed (dropout_keep_prob 0.5, gaze_rnn.py:529): engines that own a
+        connected dropout site (fc-GRU, cascade) draw a mask; gaze_grcn's sites are inert."""
         x = torch.as_tensor(np.asarray(c3d, dtype=np.float32) if not torch.is_tensor(c3d) else c3d)
         x = x.to(self.session.device, torch.float32).reshape(self.batch_size, self.n_lstm_steps, 1024, 7, 7).contiguous()
         want_probs = self.config.loss_type in ('xentropy', 'KLD')
-        logits, probs = self.engine.forward(x, want_probs=want_probs)[:2]
+        kw = {'train': True} if (train and self._has_dropout()) else {}
+        logits, probs = self.engine.forward(x, want_probs=want_probs, **kw)[:2]
         self.predicted_gazemaps_logit = logits
         self.predicted_gazemaps = probs if want_probs else logits
         return self.predicted_gazemaps
 
+    def _has_dropout(self):
+        e = getattr(self.engine, 'net', self.engine)
+        return getattr(e, 'dropout', None) is not None
+
     def compute_loss(self, gt_gazemap):
         """create_loss_and_summary (gaze_rnn.py:363-408) on the last predict()'s logits."""
-        from ..engine import softmax_xent
+        from ..engine import l2_loss, softmax_xent
         g = torch.as_tensor(np.asarray(gt_gazemap, np.float32)).to(self.session.device).contiguous()
         z = self.predicted_gazemaps_logit
         if self.config.loss_type == 'xentropy':
             return float(softmax_xent(z, g.reshape(z.shape), want_probs=False)[2].item())
         if self.config.loss_type == 'l2':
-            return float(0.5 * ((z - g.reshape(z.shape)) ** 2).sum().item() / (z.shape[0] * z.shape[1]))
+            return float(l2_loss(z.contiguous(), g.reshape(z.shape).contiguous(), z.shape[0] * z.shape[1]).item())
         raise NotImplementedError(str(self.config.loss_type))   # 'KLD' is broken in the reference too (:395-399)
 
     def single_step(self, train_mode=True, dataset=None):
@@ -171,17 +217,17 @@ class GazePredictionGRU(ModelBase):
         if self.config.loss_type in ('xentropy', 'KLD'):
             batch_maps = normalize_probability_map(batch_maps)
         if train_mode and self.config.use_flip_batch:
-            # gaze_rnn.py:504-510: mirror a random half of the clips left-right (global numpy RNG;
-            # Python-2 integer division)
+            # gaze_rnn.py:504-510: mirror a random half of the clips left-right (Python-2 integer division,
+            # SURVEY 9-Q12); drawn from this rank's seeded stream (self.flip_seed) instead of numpy's global RNG
             batch_images, batch_maps, batch_c3d = np.array(batch_images), np.array(batch_maps), np.array(batch_c3d)
-            indices = np.random.choice(self.batch_size, self.batch_size // 2, replace=False)
+            indices = self.flip_rng.choice(self.batch_size, self.batch_size // 2, replace=False)
             batch_images[indices] = batch_images[indices][:, :, :, ::-1, :]
             batch_maps[indices] = batch_maps[indices][:, :, :, ::-1]
             batch_c3d[indices] = batch_c3d[indices][:, :, :, :, ::-1]
             if isinstance(batch_fixmaps, np.ndarray) and batch_fixmaps.dtype != object:
                 batch_fixmaps = np.array(batch_fixmaps)
                 batch_fixmaps[indices] = batch_fixmaps[indices][:, :, :, ::-1]
-        self.predict(batch_c3d, batch_images)
+        self.predict(batch_c3d, batch_images, train=train_mode)
         self.loss = loss = self.compute_loss(batch_maps)
         if train_mode:
             labels = torch.as_tensor(np.ascontiguousarray(batch_maps, np.float32)).to(self.session.device)

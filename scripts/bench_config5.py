@@ -28,7 +28,11 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--c3d-chunk', type=int, default=560)
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # no launcher: start the ranks ourselves (before any GPU call)
+        raise SystemExit(rdist.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     rank, local_rank, world = rdist.env_world()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = rdist.init(backend='nccl', device=dev)

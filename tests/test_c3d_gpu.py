@@ -128,15 +128,17 @@ np.save(sys.argv[1], f.cpu().numpy())
         assert rel_err(outs[1], outs[0]) < 2e-2
 
 
-def test_full_size_launch_chain_is_clip_independent(gpu):
+def test_full_size_launch_chain_is_clip_independent(gpu, c3d_case):
     """BASELINE size: 768 windows in ONE launch chain (every layer, conv5a/5b included, then runs the persistent
-    staggered kernel; below 669 windows conv5* take the 128x128 loop) built from 8 distinct windows repeated 96
-    times.  Each replica must reproduce, bit for bit, the features of the 8-window run: windows are independent,
-    and both kernels reduce K in the same order."""
+    staggered kernels; below 669 windows conv5* take the 128x128 loop) built from 8 distinct windows repeated 96
+    times.  (i) Each replica must reproduce, bit for bit, the features of the 8-window run: windows are independent,
+    and both kernels reduce K in the same order.  (ii) Windows 0-1 are the oracle case of this module: every layer
+    of the 768-window run (i.e. the staggered kernels at bench scale, not the small-problem tile loop) is compared
+    DIRECTLY with torch_ref.c3d_forward, closing the chain oracle -> 2-window run -> 8-window run -> bench-scale run."""
     from recurrent_gaze_prediction_amd import synthetic as syn
-    from recurrent_gaze_prediction_amd.engine import C3DEngine
-    p = syn.c3d_params(21)
-    v8 = torch.tensor(syn.video_windows(23, 8), device=gpu)
+    from recurrent_gaze_prediction_amd.engine import C3DEngine, C3D_LAYER_NAMES
+    p, v2, ref_feat, ref_acts = c3d_case
+    v8 = torch.tensor(np.concatenate([v2, syn.video_windows(23, 6)]), device=gpu)
     small = C3DEngine(8, dtype='bf16', device=gpu)
     small.set_weights(p)
     f8 = small.forward(v8)[0].clone()
@@ -146,3 +148,11 @@ def test_full_size_launch_chain_is_clip_independent(gpu):
     f = big.forward(v8.repeat(96, 1, 1, 1, 1))[0]
     assert torch.isfinite(f).all() and float(f.abs().max()) > 0
     assert torch.equal(f.reshape(96, 8, -1), f8.reshape(1, 8, -1).expand(96, 8, f8[0].numel()))
+    for i, name in enumerate(C3D_LAYER_NAMES[:7]):
+        ref = np.transpose(ref_acts[name], (0, 2, 3, 4, 1))          # NCDHW -> NDHWC, windows 0-1
+        got = big.read_layer(i, 2).cpu().numpy().reshape(ref.shape)
+        e = rel_err(got, ref)
+        assert e < TOL['bf16'], '%s at 768 windows: rel err %.3e' % (name, e)
+    assert rel_err(f[:2].cpu().numpy(), ref_feat) < TOL['bf16']
+    # the last replica too (another XCD's share of the tile list)
+    assert rel_err(f[766:768].cpu().numpy(), f8[6:8].cpu().numpy()) == 0.0

@@ -78,3 +78,43 @@ def test_tf_checkpoint_mapping_roundtrip():
     with pytest.raises(ValueError):
         checkpoint.import_tf_variables(dict(checkpoint.export_tf_variables(state),
                                             **{'RGP/batch_normalization/moving_mean': np.full(128, 0.3)}))
+
+
+def test_tf_name_maps_of_the_other_three_graphs_roundtrip():
+    """fc-GRU (gaze_rnn.py:294-320, incl. the TF<=1.1 GRUCell spelling), ShallowNet (gaze_rnn.py:412-433) and the
+    cascade (gaze_grcn_cascade.py:267-423): export -> TF names (with ':0', optimizer slots mixed in) -> import."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    p = syn.fcgru_params(1, 7, 7)
+    tf_vars = {k + ':0': v for k, v in checkpoint.export_model_variables('gaze_rnn', p).items()}
+    assert 'RNN/gru_cell/gates/kernel:0' in tf_vars and 'RNN/proj_out_W:0' in tf_vars and 'proj_c3d_W:0' in tf_vars
+    tf_vars['RNN/gru_cell/gates/kernel/Adam:0'] = np.zeros(3)
+    tf_vars['global_step:0'] = np.array(7)
+    back = checkpoint.import_model_variables('gaze_rnn', tf_vars)
+    assert set(back) == set(p) and all(np.array_equal(back[k], p[k]) for k in p)
+    old = {'proj_c3d_W': p['proj_c3d_W'], 'proj_c3d_b': p['proj_c3d_b'], 'RNN/proj_out_W': p['proj_out_W'],
+           'RNN/proj_out_b': p['proj_out_b'], 'RNN/GRUCell/Gates/Linear/Matrix': p['gates_kernel'],
+           'RNN/GRUCell/Gates/Linear/Bias': p['gates_bias'], 'RNN/GRUCell/Candidate/Linear/Matrix': p['candidate_kernel'],
+           'RNN/GRUCell/Candidate/Linear/Bias': p['candidate_bias']}
+    back = checkpoint.import_model_variables('gaze_rnn', old)
+    assert all(np.array_equal(back[k], p[k]) for k in p)
+    with pytest.raises(KeyError):
+        checkpoint.import_model_variables('gaze_rnn', {k: v for k, v in old.items() if 'Candidate' not in k})
+
+    sp = syn.shallownet_params(2)
+    tf_s = checkpoint.export_model_variables('shallownet', sp)
+    assert 'ShallowNet/conv1/weights' in tf_s and 'ShallowNet/fc2/biases' in tf_s
+    tf_s['ShallowNet/fc1/weights/Adam_1'] = np.zeros(2)
+    tf_s['ShallowNet/conv1/is_training'] = np.array(0)
+    back = checkpoint.import_shallownet_variables(tf_s)
+    assert set(back) == set(sp) and all(np.array_equal(back[k], sp[k]) for k in sp)
+
+    cp = syn.cascade_params(3)
+    flat = {k: v for k, v in cp.items() if k != 'ShallowNet'}
+    flat.update({'ShallowNet/' + k: v for k, v in cp['ShallowNet'].items()})
+    tf_c = checkpoint.export_model_variables('gaze_grcn_cascade', flat)
+    assert 'RCNGaze/LastProjection/fc1/weights' in tf_c and 'RCNBottom/GRU_Conv_Wz' in tf_c and 'Upsampling/weight' in tf_c
+    back = checkpoint.import_model_variables('gaze_grcn_cascade', tf_c)
+    assert set(back) == set(flat) and all(np.array_equal(back[k], flat[k]) for k in flat)
+    # the old contrib spelling of the FC bias is accepted too
+    tf_c['RCNGaze/LastProjection/fc2/bias'] = tf_c.pop('RCNGaze/LastProjection/fc2/biases')
+    assert np.array_equal(checkpoint.import_cascade_variables(tf_c)['LastProjection/fc2_b'], flat['LastProjection/fc2_b'])

@@ -248,3 +248,38 @@ def test_oracle_reproduces_cascade_and_fcgru_golden():
     maps = torch_ref.cascade_forward(torch.tensor(frames, dtype=torch.float64),
                                      torch.tensor(syn.c3d_features(seed + 8, B, T), dtype=torch.float64), tt(syn.cascade_params(seed))).numpy()
     assert np.abs(maps - g['maps']).max() < 1e-5 * np.abs(g['maps']).max()
+
+
+def test_philox_known_answers_and_dropout_mask_rule():
+    """oracle.torch_ref.philox4x32_10 against the published Random123 known-answer vectors (kat_vectors of
+    Salmon et al., SC'11), and the keep rule of tf.nn.dropout: keep iff floor(keep_prob + u) = 1."""
+    from oracle import torch_ref as R
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = R.philox4x32_10(np.array(c), np.array(k))
+        assert tuple(int(x) for x in got) == want
+    m = R.dropout_mask(200003, 0.5, 9)
+    assert m.dtype == np.uint8 and set(np.unique(m)) == {0, 1} and abs(m.mean() - 0.5) < 0.01
+    assert R.dropout_mask(1000, 1.0, 9).all()                          # keep_prob 1: floor(1 + u) >= 1 always
+    assert abs(R.dropout_mask(200003, 0.8, 11).mean() - 0.8) < 0.01
+    # a slice of the stream can be regenerated from its offset
+    assert np.array_equal(R.dropout_mask(64, 0.5, 9, offset=4), R.dropout_mask(80, 0.5, 9)[16:])
+    x = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+    assert torch.equal(R.dropout(x, 0.5, torch.tensor([[1, 0, 1], [0, 0, 1]])), torch.tensor([[0., 0, 4], [0, 0, 10]]))
+
+
+def test_rmsprop_and_momentum_update_rules():
+    """First steps from TF's slot initial values (ms = 1, mom = 0 / accum = 0), closed form."""
+    from oracle import torch_ref as R
+    p, g = {'w': torch.tensor([1.0, -2.0], dtype=torch.float64)}, {'w': torch.tensor([0.5, -1.0], dtype=torch.float64)}
+    q, acc = R.momentum_step_tf(dict(p), g, {'w': torch.zeros(2, dtype=torch.float64)}, 0.1)
+    assert torch.allclose(q['w'], p['w'] - 0.1 * g['w']) and torch.equal(acc['w'], g['w'])
+    q1 = q['w'].clone()
+    q2, acc = R.momentum_step_tf(q, g, acc, 0.1)
+    assert torch.allclose(q2['w'], q1 - 0.1 * 1.9 * g['w'])
+    r, ms, mom = R.rmsprop_step_tf(dict(p), g, {'w': torch.ones(2, dtype=torch.float64)}, {'w': torch.zeros(2, dtype=torch.float64)}, 0.1)
+    ms1 = 0.9 + 0.1 * g['w'] ** 2
+    assert torch.allclose(ms['w'], ms1) and torch.allclose(r['w'], p['w'] - 0.1 * g['w'] / torch.sqrt(ms1 + 1e-10))
