@@ -217,6 +217,11 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
     // earlier order (all 6 DMA, then reads) kept for A/B runs.
     constexpr bool READS_FIRST = !(ABLATE & 128);
     constexpr bool B_IN_COMPUTE = !(ABLATE & 128);
+    // INTERLEAVE (ABLATE & 256): the fragment reads and the A-tile DMA go to different units (LDS array / texture
+    // addresser); issued as two blocks they serialise at ISSUE -- a wave is in-order, the 16 reads back up behind the
+    // LDS queue (~295 cycles for the 4 loading waves' 64 KB), and only then do the 4 DMA instructions start queueing
+    // behind the addresser (~300) -- so they are issued 4 reads : 1 DMA and the two queues drain side by side.
+    constexpr bool INTERLEAVE = (ABLATE & 256) != 0;
     const bool more = j + 2 < p.nk;
     int st2 = st + 2;
     if (st2 >= 3) st2 -= 3;
@@ -226,6 +231,35 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
     stamp(0);
     const char* sb = smem + ((ABLATE & 4) ? 0 : st) * STAGE;
     f32x4 af[2][MI], bf[2][NI];
+    if constexpr (INTERLEAVE) {
+      char* abuf2 = smem + st2 * STAGE;
+      auto dma_a = [&](int jj) {
+        if (more && !(ABLATE & 2))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[jj] + ko2),
+                                           (__attribute__((address_space(3))) void*)(abuf2 + (wave * A_PER_WAVE + jj) * 1024),
+                                           16, 0, 0);
+      };
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[0][i] = *(const f32x4*)(sb + a_off + i * 16 * 128 + pc0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_a(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) bf[0][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_a(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[1][i] = *(const f32x4*)(sb + a_off + i * 16 * 128 + pc1);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_a(2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) bf[1][i] = *(const f32x4*)(sb + b_off + i * 16 * 128 + pc1);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_a(3);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       af[0][i] = *(const f32x4*)(sb + a_off + i * 16 * 128 + pc0);
@@ -243,6 +277,7 @@ __global__ __launch_bounds__(512) void igemm_stagger_kernel(const IgemmParams p,
       stage_part(st2, j + 2, 1, ko2);
       if (!B_IN_COMPUTE) stage_part(st2, j + 2, 2, ko2);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // everything older than this phase's own DMA (i.e. all of K-tile j+1) must have landed
     if (more && !(ABLATE & 2)) {

@@ -14,6 +14,7 @@
 #include "igemm.hip.h"
 #include "kernels_misc.hip.h"
 #include "igemm_stagger.hip.h"
+#include "igemm_wide.hip.h"
 
 namespace rgp {
 
@@ -191,6 +192,24 @@ int launch_stagger(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   return RGP_OK;
 }
 
+// Epilogues the 256x256 kernel is instantiated for (the C3D forward / dgrad convolutions)
+template <class E> struct EpiWideOk : std::false_type {};
+template <typename TO, bool B, bool R> struct EpiWideOk<EpiStore<TO, B, R>> : std::true_type {};
+template <typename TO> struct EpiWideOk<EpiStoreMask<TO>> : std::true_type {};
+
+template <int BM, int BN, int P, class Epi, int VAR = 0>
+int launch_wide(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
+  auto kern = igemm_wide_kernel<BM, BN, P, Epi, VAR>;
+  constexpr int smem = WideSmem<BM, BN>::BYTES;
+  RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  kern<<<dim3(std::min(tiles, n_cu)), dim3(512), smem, s>>>(p, e);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 // Tile choice by output width: 128x128 (2x2 waves of 64x64) for N >= 128,
 // 128x64 (2x2 waves of 64x32) for N in (32, 64], 128x32 (4x1 waves of 32x32) below.
 template <typename T, int G, int P, class Epi>
@@ -199,10 +218,27 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
   // 2 = staggered 256x128 kernel where eligible (default, fastest measured), 0 = 128x128 only,
   // 1 = 256x128 simple loop (dev comparison)
   const int tile_cfg = dev_knob("RGP_TILE", 2);
+  // N >= 256 bf16 convolutions at C3D scale: the 256x256 tile (two thirds of the L2 -> LDS bytes per FLOP)
+  if constexpr (sizeof(T) == 2 && G == 1 && (P == 1 || P == 8) && EpiWideOk<Epi>::value) {
+    // (at least four tiles per CU: with fewer -- conv5a/b at 1024 windows: 784 -- the last, partly filled round of the
+    // persistent walk costs more than the bytes saved, and the 256x128 kernel's 1568 tiles run faster)
+    const int wide = dev_knob("RGP_WIDE", 3);
+    if (ksplit == 1 && p.nk >= 2 && p.nk <= 256) {
+      if ((wide & 1) && p.N % 256 == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 1024) {
+#ifdef RGP_DEV_KNOBS
+        if (dev_knob("RGP_WVAR", 0) == 1) return launch_wide<256, 256, P, Epi, 1>(p, e, s);
+#endif
+        return launch_wide<256, 256, P, Epi>(p, e, s);
+      }
+      if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024)
+        return launch_wide<512, 128, P, Epi>(p, e, s);
+    }
+  }
   if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
   {
 #ifdef RGP_DEV_KNOBS
     const int abl = dev_knob("RGP_ABLATE", 0);
+    if constexpr (sizeof(T) == 2) { if (abl == 256) return launch_stagger<T, P, Epi, 256>(p, e, s); }
     if constexpr (sizeof(T) == 2 && (P == 1 || P == 4)) { if (abl == 32) return launch_stagger<T, P, Epi, 32>(p, e, s); }
     if (sizeof(T) == 2 && P == 8 && abl) {
       if (abl == 1) return launch_stagger<T, P, Epi, 1>(p, e, s);

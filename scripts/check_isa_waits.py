@@ -1,11 +1,12 @@
 """Dev lint: compile the conv translation units to gfx950 assembly and flag any s_waitcnt vmcnt(...) the compiler
-placed directly in front of a K-loop fragment-read cluster (>= 8 ds_read_b128) of an igemm_stagger_kernel.
+placed directly in front of a K-loop fragment-read cluster (>= 8 ds_read_b128) of an igemm_stagger_kernel or
+igemm_wide_kernel.
 
 Why: the staggered kernel keeps two K-tiles of LDS-DMA in flight with counted waits of its own.  Whether the compiler
 adds a draining `s_waitcnt vmcnt(0)` before the fragment reads depends on its register scoreboard at the loop header
 (a global load consumed only under a condition leaves "maybe pending" registers; re-using one of them inside the loop
 forces the wait) -- it appeared and disappeared with unrelated edits during round 1.  Run after touching
-igemm_stagger.hip.h / igemm.hip.h epilogues:   python scripts/check_isa_waits.py
+igemm_stagger.hip.h / igemm_wide.hip.h / igemm.hip.h epilogues:   python scripts/check_isa_waits.py
 """
 import os, subprocess, sys, tempfile
 
@@ -16,7 +17,7 @@ CSRC = os.path.join(ROOT, 'recurrent_gaze_prediction_amd', 'csrc')
 def kernels(asm):
     lines = asm.split('\n')
     for st, l in enumerate(lines):
-        if l.startswith('_ZN3rgp20igemm_stagger_kernel') and '@' in l:
+        if (l.startswith('_ZN3rgp20igemm_stagger_kernel') or l.startswith('_ZN3rgp17igemm_wide_kernel')) and '@' in l:
             end = next(i for i in range(st, len(lines)) if 's_endpgm' in lines[i])
             yield l.split(':')[0], lines[st:end]
 
@@ -53,7 +54,7 @@ def main():
             if bad:
                 nbad += 1
                 print('STRAY WAIT', tu, name[:90], bad[:2])
-        print('%s: %d staggered kernels, %d with a compiler wait in front of the fragment reads' % (tu, n, nbad))
+        print('%s: %d staggered / wide kernels, %d with a compiler wait in front of the fragment reads' % (tu, n, nbad))
         rc |= nbad > 0
     sys.exit(rc)
 

@@ -114,7 +114,9 @@ def test_cascade_fc1_dropout_matches_oracle(gpu, dtype):
     assert rel_err(maps.cpu().numpy(), ref.detach().numpy()) < tol
     assert rel_err(plain.cpu().numpy(), ref.detach().numpy()) > 10 * tol
     grads, _ = eng.backward(maps, torch.tensor(gt, device=gpu))
-    tol_max, tol_rms = (1e-3, 3e-4) if dtype == 'f32' else (3e-1, 6e-2)
+    # bf16: a rounded forward flips single ReLU / maxout / (here also x2-scaled) dropout-survivor gates: single entries
+    # move by O(1) of their size, the RMS bound is the meaningful one (as in tests/test_cascade_gpu.py)
+    tol_max, tol_rms = (1e-3, 3e-4) if dtype == 'f32' else (8e-1, 6e-2)
     bad = {}
     for field, key in CascadeEngine.KEYS:
         r = tp[key].grad.numpy()
