@@ -5,6 +5,7 @@
 #include <map>
 
 #include "rgp_grcn_plan.h"
+#include "convgru_seq.hip.h"
 
 using namespace rgp;
 
@@ -103,9 +104,47 @@ int xconv_impl(rgp_grcn* g, hipStream_t s) {
   return launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s);
 }
 
+// All T steps in one persistent launch (convgru_seq.hip.h): recurrent filters resident in registers, state on chip.
+int seq_persistent(rgp_grcn* g, hipStream_t s) {
+  const int B = g->B, T_ = g->T, S = g->S;
+  const size_t st = (size_t)B * 49 * S;
+  RGP_HIP(hipMemsetAsync(g->ws + g->hall.off, 0, st * 4, s));                 // h_0 = 0 (gaze_grcn.py:262)
+  RGP_HIP(hipMemsetAsync(g->ws + g->seq_cnt.off, 0, g->seq_cnt.bytes, s));     // phase counters: zeroed EVERY call
+  SeqParams p;
+  p.w_zr = (const bf16_t*)(g->ws + g->gzr.w_off);
+  p.w_c = (const bf16_t*)(g->ws + g->gc.w_off);
+  p.xpre = (const float*)(g->ws + g->xpre.off);
+  p.hall = (float*)(g->ws + g->hall.off);
+  p.uall = (float*)(g->ws + g->uall.off);
+  p.rall = g->save ? (float*)(g->ws + g->rall.off) : nullptr;
+  p.call = g->save ? (float*)(g->ws + g->call.off) : nullptr;
+  p.hbn = (bf16_t*)(g->ws + g->hbn.off);
+  p.bn_gamma = g->bn_gamma;
+  p.bn_beta = g->bn_beta;
+  p.bn_inv_std = 1.0f / sqrtf(1.0f + 1e-3f);   // moving mean 0 / var 1, eps 1e-3
+  p.xch_h = (bf16_t*)(g->ws + g->xch_h.off);
+  p.xch_rh = (bf16_t*)(g->ws + g->xch_rh.off);
+  p.cnt = (unsigned*)(g->ws + g->seq_cnt.off);
+  p.B = B; p.T = T_; p.NC = g->seq_nc; p.ngroups = g->seq_groups; p.K = g->gzr.K;
+  RGP_REQUIRE(g->gzr.K == 9 * S && g->gc.K == 9 * S && g->gzr.chunk_major == 0, "convgru_seq: unexpected filter packing");
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  RGP_REQUIRE(g->seq_groups * 8 <= n_cu, "convgru_seq: %d workgroups must be co-resident on %d CUs", g->seq_groups * 8, n_cu);
+  if (g->seq_nc == 1) {
+    RGP_TRY(ensure_dyn_smem((const void*)convgru_seq_kernel<4>, SEQ_SMEM));
+    convgru_seq_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
+  } else {
+    RGP_TRY(ensure_dyn_smem((const void*)convgru_seq_kernel<7>, SEQ_SMEM));
+    convgru_seq_kernel<7><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
+  }
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 template <typename T>
 int seq_impl(rgp_grcn* g, hipStream_t s) {
   const int B = g->B, T_ = g->T, S = g->S;
+  if (sizeof(T) == 2 && g->seq_groups > 0 && dev_knob("RGP_SEQ", 1)) return seq_persistent(g, s);
   const size_t st = (size_t)B * 49 * S;  // fp32 elements per state snapshot
   RGP_HIP(hipMemsetAsync(g->ws + g->hp.off, 0, g->hp.bytes, s));      // h_0 = 0 (gaze_grcn.py:262)
   RGP_HIP(hipMemsetAsync(g->ws + g->hall.off, 0, st * 4, s));
@@ -317,6 +356,15 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->gtoep = take(a, (size_t)7 * 16 * 704 * 4);
   g->bias16 = take(a, 16 * 4);
   g->frame_loss = take(a, (size_t)F * 4);
+  // persistent sequence kernel (convgru_seq.hip.h): the reference cell (128 state channels on 7x7), bf16 operands,
+  // up to 2 clips per group of 8 workgroups and at most 32 groups (= the 256 CUs)
+  if (dtype == RGP_BF16 && S == 128 && batch <= 64) {
+    g->seq_nc = (batch + 31) / 32;
+    g->seq_groups = (batch + g->seq_nc - 1) / g->seq_nc;
+    g->xch_h = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
+    g->xch_rh = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
+    g->seq_cnt = take(a, (size_t)g->seq_groups * 2 * n_steps * 4);
+  }
   if (g->save) {
     const int rc = grcn_bwd_plan(g, a);
     if (rc != RGP_OK) { delete g; return rc; }

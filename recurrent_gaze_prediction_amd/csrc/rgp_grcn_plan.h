@@ -16,6 +16,8 @@ struct rgp_grcn {
   std::vector<int> tab_pad9_P, tab_pad9_S, tab_pad27, tab_pad55, tab_lin49_3S, tab_lin49_S;
   size_t o_pad9_P = 0, o_pad9_S = 0, o_pad27 = 0, o_pad55 = 0, o_lin49_3S = 0, o_lin49_S = 0;
   Buf xt, E, xpre, hall, uall, rall, call, hp, rhp, hbn, D1, D2, gfold, frame_loss, gtoep, bias16;
+  Buf xch_h, xch_rh, seq_cnt;   // persistent ConvGRU sequence kernel: exchange images [groups][98][128] + phase counters
+  int seq_nc = 0, seq_groups = 0;   // clips per group / groups (0 = the per-step path)
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool weights_set = false;
