@@ -15,6 +15,7 @@
 #include "bwd_kernels.hip.h"
 #include "rgp_grcn_plan.h"
 #include "wgrad_launch.h"
+#include "convgru_bptt.hip.h"
 
 using namespace rgp;
 
@@ -26,6 +27,7 @@ struct GrcnBwd {
   size_t o_y = 0, o_pad3S = 0, o_pad2S = 0, o_koff_c = 0;
   long long M = 0, M2 = 0, Mp = 0, M2p = 0;
   Buf dz, frame_sum, dgp, gp, dd2, dd1, dy, dh_head, dh_carry, drh, dcp_pad, dzr_pad, dxpre, dxpre_pad, dE, rh_all;
+  Buf xch_c, xch_z, xch_r, bptt_cnt;       // persistent BPTT kernel (convgru_bptt.hip.h): exchange images + phase counters
   Buf hp_all, rhp_all, dzb, ptoep, sq_partial;   // dzb / ptoep: blocked dz and the Toeplitz partial sums of the head filter gradient     // halo-padded h_{t-1} and r.h_{t-1} of every step, [t][b][9][9][S] (wgrad operands)
   rgp_grcn_weights w;   // forward weights (device fp32) as last set
 };
@@ -172,9 +174,30 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const float inv = 1.0f / sqrtf(1.0f + 1e-3f);
   bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(Fp(b->dy), Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma,
                                                   (float*)gr->bn_beta, Fp(b->dh_head), B, T_, S, inv);
-  // 6. BPTT: t = T-1 .. 0
+  // 6. BPTT: t = T-1 .. 0 -- one persistent launch where the plan allows it (bf16, the reference cell, <= 64 clips)
   const int ew_blocks = (int)std::min<size_t>((st + 255) / 256, 4096);
-  for (int t = T_ - 1; t >= 0; --t) {
+  const bool persistent = sizeof(T) == 2 && g->seq_groups > 0 && dev_knob("RGP_SEQ", 1);
+  if (persistent) {
+    RGP_HIP(hipMemsetAsync(ws + b->bptt_cnt.off, 0, b->bptt_cnt.bytes, s));      // phase counters: zeroed EVERY call
+    BpttParams q;
+    q.w_c = (const bf16_t*)(ws + b->b_c.w_off);
+    q.w_zr = (const bf16_t*)(ws + b->b_zr.w_off);
+    q.dh_head = Fp(b->dh_head); q.hall = Fp(g->hall); q.uall = Fp(g->uall); q.rall = Fp(g->rall); q.call = Fp(g->call);
+    q.dxpre = Fp(b->dxpre);
+    q.xch_c = (bf16_t*)(ws + b->xch_c.off); q.xch_z = (bf16_t*)(ws + b->xch_z.off); q.xch_r = (bf16_t*)(ws + b->xch_r.off);
+    q.cnt = (unsigned*)(ws + b->bptt_cnt.off);
+    q.B = B; q.T = T_; q.NC = g->seq_nc; q.ngroups = g->seq_groups;
+    RGP_REQUIRE(b->b_c.K == 9 * S && b->b_zr.K == 18 * S, "convgru_bptt: unexpected filter packing");
+    if (g->seq_nc == 1) {
+      RGP_TRY(ensure_dyn_smem((const void*)convgru_bptt_kernel<4>, SEQ_SMEM));
+      convgru_bptt_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(q);
+    } else {
+      RGP_TRY(ensure_dyn_smem((const void*)convgru_bptt_kernel<7>, SEQ_SMEM));
+      convgru_bptt_kernel<7><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(q);
+    }
+    RGP_HIP(hipGetLastError());
+  }
+  for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
     gru_bwd1_kernel<T><<<ew_blocks, 256, 0, s>>>(Fp(b->dh_head) + (size_t)t * st, Fp(b->dh_carry), h_prev,
                                                   Fp(g->uall) + (size_t)t * st, Fp(g->call) + (size_t)t * st, Fp(b->dxpre),
@@ -361,6 +384,12 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   b->dxpre_pad = take(a, (size_t)F * 81 * 3 * S * es);
   b->dE = take(a, (size_t)(b->M + 1) * P * es);        // + a leading zero row
   b->rh_all = take(a, st * T_);
+  if (g->seq_groups > 0) {
+    b->xch_c = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
+    b->xch_z = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
+    b->xch_r = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
+    b->bptt_cnt = take(a, (size_t)g->seq_groups * 2 * T_ * 4);
+  }
   b->dzb = take(a, ((size_t)F * 49 * 64 + 256) * es);
   b->ptoep = take(a, (size_t)7 * 16 * 704 * 4);
   b->hp_all = take(a, (size_t)T_ * B * 81 * S * es);
