@@ -38,11 +38,25 @@ C3D_FLOPS = {n: 2.0 * d * h * h * 27 * ci * co for n, ci, co, d, h in C3D_LAYERS
 HEAD_FLOPS = {'proj': 51.38e6, 'xconv': 173.41e6, 'convgru_seq': 43.35e6, 'head': 20.07e6 + 54.17e6 + 90.35e6 + 0.06e6}
 HEAD_FLOPS_FRAME = 432.79e6
 C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
-# kernel instantiation that executes each C3D layer (template igemm_kernel<T,BM,BN,WM,WN,G,P,Epi>)
-C3D_KERNEL_GROUP = {'conv1a': 'conv1a_pool_bf16_kernel', 'conv2a': 'igemm_stagger_kernel<256x128,pool8>',
-                    'conv3b': 'igemm_stagger_kernel<256x128,pool8>', 'conv4b': 'igemm_stagger_kernel<256x128,pool8>',
-                    'conv3a': 'igemm_stagger_kernel<256x128,pool1>', 'conv4a': 'igemm_stagger_kernel<256x128,pool1>',
-                    'conv5a': 'igemm_stagger_kernel<256x128,pool1>', 'conv5b': 'igemm_stagger_kernel<256x128,pool1>'}
+# kernel instantiation that executes each C3D layer at `n` windows per launch (mirrors launch_igemm in csrc/rgp_host.h)
+C3D_POOL = {'conv1a': 4, 'conv2a': 8, 'conv3a': 1, 'conv3b': 8, 'conv4a': 1, 'conv4b': 8, 'conv5a': 1, 'conv5b': 1}
+
+
+def c3d_kernel_group(name, n_windows, dtype='bf16'):
+    ci, co, d, h = next((ci, co, d, h) for nm, ci, co, d, h in C3D_LAYERS if nm == name)
+    if name == 'conv1a' and dtype == 'bf16':
+        return 'conv1a_pool_bf16_kernel'
+    rows = n_windows * d * h * h
+    pool = 'pool%d' % C3D_POOL[name]
+    if dtype == 'bf16' and co % 256 == 0 and -(-rows // 256) * (co // 256) >= 1024:
+        return 'igemm_wide_kernel<256x256,%s>' % pool
+    if dtype == 'bf16' and co == 128 and -(-rows // 512) >= 1024:
+        return 'igemm_wide_kernel<512x128,%s>' % pool
+    if rows >= 65536:
+        return 'igemm_stagger_kernel<256x128,%s>' % pool
+    return 'igemm_kernel<128x128,%s>' % pool
+
+
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
 
 
@@ -204,7 +218,7 @@ def main():
             groups = {}
             for name, _, _, _, _ in C3D_LAYERS:
                 ms, calls = cprof[name]
-                grp = groups.setdefault(C3D_KERNEL_GROUP[name], [0.0, 0.0, 0])
+                grp = groups.setdefault(c3d_kernel_group(name, min(args.c3d_chunk, F), args.dtype), [0.0, 0.0, 0])
                 grp[0] += ms
                 grp[1] += C3D_FLOPS[name] * F * args.steps          # flops executed in the timed region
                 grp[2] += calls
@@ -218,16 +232,10 @@ def main():
             flops = HEAD_FLOPS[kname] * F * args.steps
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
-        # this is the committed rocprofv3 measurement (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # same command, gfx950 x2 FETCH correction applied: profiles/r01_traffic_dominant_kernel.json),
-        # scaled by the windows one launch processes here; null when it does not describe this run.
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process.  `traffic` is null
+        # unless this very invocation runs under rocprofv3 --pmc and a wrapper fills it in afterwards
+        # (scripts/pmc_summary.py writes profiles/r02_traffic_dominant_kernel.json from such a run; DESIGN.md quotes it).
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic_dominant_kernel.json')
-        if c3d is not None and args.dtype == 'bf16' and os.path.exists(tpath):
-            tr = json.load(open(tpath))
-            if tr.get('kernel') == kname:
-                traffic = round(tr['hbm_bytes_per_window'] * min(args.c3d_chunk, F))
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(achieved / peak, 4), 'traffic': traffic, 'kernel': kname,
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),

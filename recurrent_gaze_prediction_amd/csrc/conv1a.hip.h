@@ -28,6 +28,9 @@
 namespace rgp {
 
 struct Conv1aParams {
+  const float* video;   // FUSED variant: the caller's mean-subtracted clip windows [n][16][112][112][3] fp32, read directly
+                        // (the separate video_prep pass -- 2.4 MB read + 1.9 MB written per window, 0.93 ms per 1024
+                        // windows at HBM rate -- is folded into the patch fetch)
   const bf16_t* in;     // [n][18][114][116][4]
   const bf16_t* wp;     // [64][128]
   const float* bias;    // [64]
@@ -51,12 +54,27 @@ constexpr int C1_CPR = C1_ROWB / 16;                      // 58 chunks per row
 constexpr int C1_NLD = (C1_CHUNKS + 255) / 256;           // 7 loads per thread
 constexpr int C1_TILES = C1_JROWS * C1_XG;                // 28 wave tiles per job
 constexpr int C1_SMEM = 2 * C1_PATCH + 4 * 8 * 72 * 2 + 4 * 8 * 72;
+// FUSED variant: LDS patch rows of 118 pixel slots (944 B): slot 1 = x -1 (zero), slots 2..113 = x 0..111, so that the
+// 4-pixel groups converted from fp32 land on 16-byte boundaries; slots 0, 1 and 114..117 stay zero for the whole kernel
+constexpr int C1F_WPL = 118;
+constexpr int C1F_PATCH = 3 * C1_PROWS * C1F_WPL * 8;     // 28 320 bytes
+constexpr int C1F_GROUPS = 3 * C1_PROWS * 28;             // 840 groups of 4 pixels (12 floats = three 16-byte loads)
+constexpr int C1F_NLD = (C1F_GROUPS + 255) / 256;         // 4 per thread
+constexpr int C1F_SMEM = 2 * C1F_PATCH + 4 * 8 * 72 * 2 + 4 * 8 * 72;
 
+template <bool FUSED>
 static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aParams p) {
+  constexpr int WPL = FUSED ? C1F_WPL : C1_WP;             // LDS patch row pitch in pixel slots
+  constexpr int XS = FUSED ? 1 : 0;                        // slot of x = -1
+  constexpr int PATCH = FUSED ? C1F_PATCH : C1_PATCH;
   extern __shared__ __attribute__((aligned(16))) char c1_smem[];
-  char* patch = c1_smem;                                                   // [2][C1_PATCH]
-  bf16_t* s_out = (bf16_t*)(c1_smem + 2 * C1_PATCH);                       // per wave: 8 px x (64 ch + 8 pad)
+  char* patch = c1_smem;                                                   // [2][PATCH]
+  bf16_t* s_out = (bf16_t*)(c1_smem + 2 * PATCH);                          // per wave: 8 px x (64 ch + 8 pad)
   unsigned char* s_arg = (unsigned char*)(s_out + 4 * 8 * 72);
+  if constexpr (FUSED) {      // the x-halo slots are never written afterwards
+    for (int i = threadIdx.x; i < 2 * PATCH / 16; i += 256) ((u32x4*)patch)[i] = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,11 +126,61 @@ static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const C
     for (int u = 0; u < C1_NLD; ++u)
       if (tid + 256 * u < C1_CHUNKS) *(u32x4*)(buf + (tid + 256 * u) * 16) = pf[u];
   };
+  // FUSED: group q = tid + 256 u of the patch = row q / 28 (plane kz = row / 10, row ry = row % 10), pixels 4 (q % 28)..+3
+  // -> three 16-byte loads of 12 floats from the fp32 window; rows / planes outside the window give zeros
+  // (row / group are recomputed from tid where needed: 8 fewer live VGPRs in a kernel at the 256-register limit)
+  auto grp = [&](int u, int& row, int& xg) {
+    int q = tid + 256 * u;
+    if (q >= C1F_GROUPS) q = C1F_GROUPS - 1;                 // duplicate, never written
+    row = (q * 2341) >> 16;                                  // q / 28 for q < 840
+    xg = q - row * 28;
+  };
+  auto fetch_f = [&](long long j, f32x4 (&pf)[C1F_NLD][3]) {
+    const int yq = (int)(j % C1_YQ);
+    const int z = (int)((j / C1_YQ) % C1_D);
+    const long long n = j / C1_JOBS_PER_WINDOW;
+#pragma unroll
+    for (int u = 0; u < C1F_NLD; ++u) {
+      int row, xg;
+      grp(u, row, xg);
+      const int kz = row / C1_PROWS, ry = row - kz * C1_PROWS;
+      const int zz = z + kz - 1, yy = yq * 2 * C1_JROWS + ry - 1;
+      const bool ok = zz >= 0 && zz < C1_D && yy >= 0 && yy < C1_H;
+      const float* src = p.video + (((n * C1_D + (ok ? zz : 0)) * C1_H + (ok ? yy : 0)) * (long long)C1_H + 4 * xg) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pf[u][k] = ok ? *(const f32x4*)(src + 4 * k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto park_f = [&](char* buf, const f32x4 (&pf)[C1F_NLD][3]) {
+#pragma unroll
+    for (int u = 0; u < C1F_NLD; ++u) {
+      if (tid + 256 * u < C1F_GROUPS) {
+        const float f[12] = {pf[u][0][0], pf[u][0][1], pf[u][0][2], pf[u][0][3], pf[u][1][0], pf[u][1][1],
+                             pf[u][1][2], pf[u][1][3], pf[u][2][0], pf[u][2][1], pf[u][2][2], pf[u][2][3]};
+        // two packed conversions per pixel (v_cvt_pk_bf16_f32): {c0, c1}, {c2, 0}
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        u32x4 w0, w1;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const f32x2_ a = {f[3 * px], f[3 * px + 1]}, b = {f[3 * px + 2], 0.f};
+          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_));
+          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_));
+          if (px < 2) { w0[2 * px] = lo; w0[2 * px + 1] = hi; } else { w1[2 * (px - 2)] = lo; w1[2 * (px - 2) + 1] = hi; }
+        }
+        int row, xg;
+        grp(u, row, xg);
+        char* dst = buf + (row * WPL + 2 + 4 * xg) * 8;
+        *(u32x4*)dst = w0;
+        *(u32x4*)(dst + 16) = w1;
+      }
+    }
+  };
 
   // per-lane fragment addressing inside a patch (bytes).  Row r of an m-tile: window w = frow>>2,
   // dy = (frow>>1)&1, dx = frow&1; K-chunk 4s+kg = taps 2(4s+kg), 2(4s+kg)+1 (taps >= 27 carry zero weights).
   const int r_w = frow >> 2, r_dy = (frow >> 1) & 1, r_dx = frow & 1;
-  const int lane_base = (r_dy * C1_WP + 2 * r_w + r_dx) * 8;
+  const int lane_base = (r_dy * WPL + 2 * r_w + r_dx + XS) * 8;
   int toff[4][2];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -121,12 +189,12 @@ static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const C
       int tap = 2 * (4 * s + kg) + j;
       if (tap > 26) tap = 0;
       const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-      toff[s][j] = ((kz * C1_PROWS + ky) * C1_WP + kx) * 8 + lane_base;
+      toff[s][j] = ((kz * C1_PROWS + ky) * WPL + kx) * 8 + lane_base;
     }
 
   auto load_frags = [&](const char* buf, int tile, f32x4 (&a)[2][4]) {
     const int yl = tile / C1_XG, xg = tile - yl * C1_XG;
-    const char* tb = buf + (2 * yl * C1_WP + 16 * xg) * 8;
+    const char* tb = buf + (2 * yl * WPL + 16 * xg) * 8;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -185,15 +253,18 @@ static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const C
   };
 
   u32x4 pf[C1_NLD];
-  fetch(job, pf);
-  park(patch, pf);
+  f32x4 pff[C1F_NLD][3];
+  if constexpr (FUSED) { fetch_f(job, pff); park_f(patch, pff); }
+  else { fetch(job, pf); park(patch, pf); }
   __syncthreads();
   int cur = 0;
   while (true) {
     const long long nxt = job + nslot;
     const bool more = nxt < job_end;
-    if (more) fetch(nxt, pf);                       // in flight while this job's 7 tiles per wave compute
-    const char* buf = patch + cur * C1_PATCH;
+    if (more) {                                     // in flight while this job's 7 tiles per wave compute
+      if constexpr (FUSED) fetch_f(nxt, pff); else fetch(nxt, pf);
+    }
+    const char* buf = patch + cur * PATCH;
     f32x4 a[2][2][4];
     load_frags(buf, wave, a[0]);
 #pragma unroll
@@ -202,7 +273,7 @@ static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const C
       process(job, wave + 4 * i, a[i & 1]);
     }
     if (!more) break;
-    park(patch + (cur ^ 1) * C1_PATCH, pf);
+    if constexpr (FUSED) park_f(patch + (cur ^ 1) * PATCH, pff); else park(patch + (cur ^ 1) * PATCH, pf);
     __syncthreads();                                // next patch visible; everybody is done with this one
     cur ^= 1;
     job = nxt;

@@ -44,8 +44,9 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
 }
 
 // bf16 conv1a: dedicated register-resident-filter kernel (conv1a.hip.h)
-int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s) {
+int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video = nullptr) {
   Conv1aParams p;
+  p.video = video;
   p.in = (const bf16_t*)(c->ws + c->act_off[0]);
   p.wp = (const bf16_t*)(c->ws + c->L[0].w_off);
   p.bias = c->bias[0];
@@ -53,7 +54,8 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s) {
   p.argmax = c->save ? (unsigned char*)(c->ws + c->B[0].argmax_off) : nullptr;
   p.n_windows = n;
   // two 4-wave blocks per CU, a multiple of 8 so that every XCD gets the same number of job slots
-  conv1a_pool_bf16_kernel<<<512, 256, C1_SMEM, s>>>(p);
+  if (video) conv1a_pool_bf16_kernel<true><<<512, 256, C1F_SMEM, s>>>(p);      // reads the fp32 windows directly
+  else conv1a_pool_bf16_kernel<false><<<512, 256, C1_SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
@@ -80,18 +82,22 @@ template <typename T>
 int forward_chunk(rgp_c3d* c, const float* video, const FrameSrc* fs, int n, float* features, void* rows, hipStream_t s) {
   const long long npix = (long long)n * 16 * 112 * 112;
   const int blocks = (int)std::min<long long>((npix + 255) / 256, 65536);
+  // bf16 inference from fp32 windows: conv1a converts and pads the input inside its patch fetch (no act0 image).  A
+  // training plan keeps act0: the conv1a filter gradient reads it.
+  const bool fused_in = sizeof(T) == 2 && !fs && !c->save && dev_knob("RGP_C1FUSE", 1);
   int pid = c->prof.begin(8, s);
   if (fs)
     frames_prep_kernel<T><<<blocks, 256, 0, s>>>(fs->frames, fs->fh, fs->fw, (const int*)(c->ws + c->starts_off), fs->mean,
                                                  (T*)(c->ws + c->act_off[0]), nullptr, npix);
-  else
+  else if (!fused_in)
     video_prep_kernel<T><<<blocks, 256, 0, s>>>(video, (T*)(c->ws + c->act_off[0]), npix, 16, 112, 112);
   RGP_HIP(hipGetLastError());
   c->prof.end(pid, s);
   c->last_n = n;
   for (int i = 0; i < 8; ++i) {
     pid = c->prof.begin(i, s);
-    RGP_TRY(layer_dispatch<T>(c, i, n, s));
+    if (i == 0 && fused_in) RGP_TRY(run_conv1a_bf16(c, n, s, video));
+    else RGP_TRY(layer_dispatch<T>(c, i, n, s));
     c->prof.end(pid, s);
   }
   const T* r = (const T*)(c->ws + c->act_off[8]);

@@ -65,8 +65,14 @@ template <typename T> __device__ __forceinline__ int wg_swz_y(int r) {
   return sizeof(T) == 2 ? 2 * ((r & 3) | (((r >> 3) & 1) << 2)) : 0;
 }
 
-template <typename T, int G, int WNT>
+// STAG (bf16, WNT = 8, one block per CU): the two wave groups 0-3 / 4-7 (partners on a SIMD) run half a step apart,
+//   LOAD(s): fragment reads of step s, DMA of step s+2, counted vmcnt, barrier     COMPUTE(s): 32 MFMAs, barrier
+// so one wave of a SIMD is in its MFMAs while the other reads (igemm_stagger.hip.h).  Without it the 256-wide tile
+// -- a third fewer LDS-DMA bytes per FLOP than two co-resident 128-wide blocks -- loses what it saves to exposed
+// LDS latency (its two waves per SIMD read, wait and compute in lockstep).
+template <typename T, int G, int WNT, bool STAG = false>
 __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad_kernel(const WgradParams p) {
+  static_assert(!STAG || (WNT == 8 && sizeof(T) == 2), "staggered schedule: bf16, 256-wide tile");
   constexpr int ESZ = sizeof(T);
   constexpr int BKE = Elem<T>::BKE;               // filter rows per K-chunk (64 bf16, 32 fp32)
   constexpr int CI = BKE / 16;                    // 16-row tiles per chunk
@@ -270,16 +276,106 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
     }
   };
 
+  // STAG: the same reads / MFMAs as compute(), split around the group barrier (fragments live in registers across it)
+  i32x2 s_al[4], s_ah[4], s_bl[WNT], s_bh[WNT];
+  auto stag_reads = [&](int buf) {
+    if constexpr (STAG) {
+      const char* xb = smem + buf * S::STAGE + wk * 4096;
+      const char* yb = smem + buf * S::STAGE + S::XB;
+      const int q = fcol >> 2, pp = fcol & 3;
+      const int row = 8 * g + q;
+      const int sx = (wg_swz_x<T>(row) >> 1), sy = (wg_swz_y<T>(row) >> 1);
+      const unsigned xa = lds_base + (unsigned)(xb - smem) + row * 128 + pp * 8;
+      const unsigned ya = lds_base + (unsigned)(yb - smem) + row * YROW + pp * 8;
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:512\n\t"
+          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:512\n\t"
+          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:512"
+          : "=&v"(s_al[0]), "=&v"(s_ah[0]), "=&v"(s_al[1]), "=&v"(s_ah[1]), "=&v"(s_al[2]), "=&v"(s_ah[2]), "=&v"(s_al[3]), "=&v"(s_ah[3])
+          : "v"(xa + ((0 ^ sx) * 32)), "v"(xa + ((1 ^ sx) * 32)), "v"(xa + ((2 ^ sx) * 32)), "v"(xa + ((3 ^ sx) * 32))
+          : "memory");
+#pragma unroll
+      for (int jb = 0; jb < WNT; jb += 4)
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
+            "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:2048"
+            : "=&v"(s_bl[jb]), "=&v"(s_bh[jb]), "=&v"(s_bl[jb + 1]), "=&v"(s_bh[jb + 1]), "=&v"(s_bl[jb + 2]), "=&v"(s_bh[jb + 2]),
+              "=&v"(s_bl[jb + 3]), "=&v"(s_bh[jb + 3])
+            : "v"(ya + (((wn * WNT + jb + 0) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 1) ^ sy) * 32)),
+              "v"(ya + (((wn * WNT + jb + 2) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 3) ^ sy) * 32))
+            : "memory");
+    }
+  };
+  auto stag_mma = [&]() {
+    if constexpr (STAG) {
+      // the fragment registers are valid only behind the lgkmcnt(0) of the LOAD phase: re-define them here
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(s_al[i]), "+v"(s_ah[i]));
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) asm volatile("" : "+v"(s_bl[j]), "+v"(s_bh[j]));
+      f32x4 a[CI], b[WNT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const i32x4 va = {s_al[i][0], s_al[i][1], s_ah[i][0], s_ah[i][1]};
+        a[i] = __builtin_bit_cast(f32x4, va);
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const i32x4 vb = {s_bl[j][0], s_bl[j][1], s_bh[j][0], s_bh[j][1]};
+        b[j] = __builtin_bit_cast(f32x4, vb);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < CI; ++i)
+        if (i < ci_n) {
+#pragma unroll
+          for (int j = 0; j < WNT; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
   // ---- 3-stage ring: steps s+1 and s+2 are in flight while step s is consumed.  Steps beyond the
   // block's range are issued too (they fetch zeros), so the vmcnt arithmetic is uniform. ----
   issue(0);
   issue(1);
+  if constexpr (STAG) {
+    // Hazards as in igemm_stagger.hip.h (h = half-step; group A loads step s at h = 2s, computes at 2s+1; B one later):
+    //  RAW  step s is read from h = 2s on; its DMA was issued in LOAD(s-2) and every wave passed vmcnt(PER_STEP) for it
+    //       in LOAD(s-1) before that phase's barrier (A: end of 2s-2, B: end of 2s-1).
+    //  WAR  the DMA of step s+2 overwrites the stage of step s-1, last read in LOAD(s-1) (A: 2s-2, B: 2s-1, each followed
+    //       by lgkmcnt(0) + barrier); it is issued at h >= 2s.
+    const bool group_b = wave >= 4;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");   // step 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (group_b) __builtin_amdgcn_s_barrier();
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < nsteps; ++s) {
+      stag_reads(s % 3);
+      __builtin_amdgcn_sched_barrier(0);
+      issue((s + 2) % 3);                                            // (beyond the range: zeros, uniform vmcnt arithmetic)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_STEP) : "memory");   // step s+1 landed, fragments in registers
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      stag_mma();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!group_b) __builtin_amdgcn_s_barrier();
+  } else {
 #pragma clang loop unroll(disable)
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
     if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
     if (!(p.ablate & 2)) issue((s + 2) % 3);
     if (!(p.ablate & 1) && ci_n > 0) compute(s % 3);
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

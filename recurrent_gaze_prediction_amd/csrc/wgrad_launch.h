@@ -8,9 +8,9 @@
 
 namespace rgp {
 
-template <typename T, int G, int WNT>
+template <typename T, int G, int WNT, bool STAG = false>
 int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
-  auto kern = wgrad_kernel<T, G, WNT>;
+  auto kern = wgrad_kernel<T, G, WNT, STAG>;
   constexpr int smem = WgradSmem<T, WNT>::BYTES;
   constexpr int BN = 32 * WNT;
   RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
@@ -38,6 +38,12 @@ int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     const int wide = dev_knob("RGP_WG_WIDE", 1);
     const int narrow_tiles = ((p.nk + 3) / 4) * ((p.N + 127) / 128);
+#ifdef RGP_DEV_KNOBS
+    // RGP_WG_WIDE=3: staggered 256-wide tile whenever N % 256 == 0.  Measured on the fine-tune step (B16 x T16, one
+    // box, interleaved): 60.3 / 60.3 ms default vs 60.6 / 60.3 ms -- no gain: the loop is bound by its one transposing
+    // LDS read per MFMA (reads + MFMA alone run at 0.9 PFLOP/s), not by the overlap of its phases.  Dev build only.
+    if (G == 1 && wide == 3 && p.N % 256 == 0) return launch_wgrad_t<T, G, 8, G == 1>(p, s);
+#endif
     if (wide && p.N % 256 == 0 && (wide == 2 || narrow_tiles <= 64)) return launch_wgrad_t<T, G, 8>(p, s);
   }
   return launch_wgrad_t<T, G, 4>(p, s);
