@@ -19,8 +19,10 @@
 // is stored write-through (sc1) as 16-byte rows, every storing wave drains (`s_waitcnt vmcnt(0)`), the workgroup
 // barriers, ONE lane adds to the group's monotonic phase counter; consumers poll that counter with sc1 loads from one
 // lane (bounded, with s_sleep), barrier, and read the payload with sc1 loads only.  Counters are zeroed by a
-// hipMemsetAsync ahead of the launch.  All 8 x ngroups <= 256 workgroups (256 threads each) must be resident:
-// a member that never arrives makes its group time out, NaN-poison its final state and leave (no hang).
+// hipMemsetAsync ahead of the launch.  All 8 x ngroups <= 256 workgroups (256 threads, 157 KB of LDS: one per CU) must
+// be resident together; the host checks the CU count and falls back to per-step launches otherwise.  A member that
+// never arrives (e.g. two such launches interleaved on one device from different streams: keep ONE in flight per
+// device) makes its group time out after ~1 s, NaN-poison its final state and leave -- a loud failure, never a hang.
 #pragma once
 #include "igemm.hip.h"
 
@@ -178,10 +180,12 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
   // in this CU's memory pipeline; they go BEFORE the publish, overlapped with the gate math.)
   auto wait_load = [&](int ph, const bf16_t* xch, char* img) {
     if (tid == 0) {
+      // bounded: ~1 s; a workgroup that timed out once stops waiting altogether (its results are poisoned below), so a
+      // group with a missing member costs a second, not a second per phase
       int spins = 0;
-      while (__hip_atomic_load(cnt + ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
+      while (!s_timeout && __hip_atomic_load(cnt + ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) { s_timeout = 1; break; }
+        if (++spins > (1 << 20)) { s_timeout = 1; break; }
       }
     }
     __syncthreads();

@@ -55,6 +55,7 @@ template <int BM_, int BN_> struct WideSmem {
 template <int BM, int BN, int P, class Epi, int VAR = 0>
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, const EpiParams e) {
   constexpr bool B_IN_LOAD = (VAR & 1) != 0;                  // dev: the B-part of the DMA rides in LOAD too
+  constexpr bool A_SPLIT = (VAR & 2) != 0;                    // dev: half of the A-part rides in COMPUTE (512-row tile: 4 + 1 -> 2 + 3)
   using T = bf16_t;
   using Smem = WideSmem<BM, BN>;
   constexpr int NT = 512;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   constexpr int A_BYTES = BM * 64;
   constexpr int A_PER = BM / 16 / 8, B_PER = BN / 16 / 8;    // 1-KiB DMA blocks per wave: 2 + 2 or 4 + 1
   // counted waits: in LOAD(s), after the A-part of sub-tile s+AHEAD, everything up to sub-tile s+1 must have landed
-  constexpr int VM_LOOP = (AHEAD - 2) * (A_PER + B_PER) + (B_IN_LOAD ? A_PER + B_PER : A_PER);
+  constexpr int A_LOAD = A_SPLIT ? A_PER / 2 : A_PER;         // A-part DMA instructions issued in LOAD
+  constexpr int VM_LOOP = (AHEAD - 2) * (A_PER + B_PER) + (B_IN_LOAD ? A_PER + B_PER : A_LOAD);
   constexpr int VM_PRO = (AHEAD - 1) * (A_PER + B_PER);
   static_assert(BM % 128 == 0 && BN % 64 == 0 && (BM / WTM) * WN == 8, "8 waves of 128 x 64");
 
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
   const char* a_src[A_PER];
   const char* b_src[B_PER];
   // A-part / B-part of one sub-tile's DMA (A_PER + B_PER of this wave's instructions)
-  auto dma_a = [&](int slot, int s, long long ko) {
+  auto dma_a = [&](int slot, int s, long long ko, int j0, int j1) {
     char* abuf = smem + slot * SLOT;
 #pragma unroll
-    for (int j = 0; j < A_PER; ++j)
+    for (int j = j0; j < j1; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + ko),
                                        (__attribute__((address_space(3))) void*)(abuf + (wave * A_PER + j) * 1024), 16, 0, 0);
   };
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
     // ---- prologue: sub-tiles 0 .. AHEAD-1 in flight, sub-tile 0 landed for everybody (nsub >= 4: host-checked) ----
     auto koff_bytes = [&](int s) { return (long long)s_koff[s >> 1] * 2 + (s & 1) * 64; };
 #pragma unroll
-    for (int s0 = 0; s0 < AHEAD; ++s0) { dma_a(s0, s0, koff_bytes(s0)); dma_b(s0, s0); }
+    for (int s0 = 0; s0 < AHEAD; ++s0) { dma_a(s0, s0, koff_bytes(s0), 0, A_PER); dma_b(s0, s0); }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PRO) : "memory");
     __builtin_amdgcn_s_barrier();
     if (group_b) __builtin_amdgcn_s_barrier();      // run one half-step behind group A
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
       for (int i = 0; i < NI; ++i) bf[i] = *(const f32x4*)(sb + b_off + i * 1024);
       if (more) {
         __builtin_amdgcn_sched_barrier(0);
-        dma_a(slot3, s + AHEAD, ko3);
+        dma_a(slot3, s + AHEAD, ko3, 0, A_LOAD);
         if constexpr (B_IN_LOAD) dma_b(slot3, s + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
         // all of sub-tile s+1 landed: outstanding may be the parts of s+2 .. s+AHEAD issued so far
@@ -210,6 +212,11 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p, co
         if (!B_IN_LOAD && more && i == 1) {
           __builtin_amdgcn_sched_barrier(0);
           dma_b(slot3, s + AHEAD);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (A_SPLIT && more && i == 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          dma_a(slot3, s + AHEAD, ko3, A_LOAD, A_PER);
           __builtin_amdgcn_sched_barrier(0);
         }
       }

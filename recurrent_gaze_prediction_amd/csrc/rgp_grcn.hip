@@ -104,6 +104,16 @@ int xconv_impl(rgp_grcn* g, hipStream_t s) {
   return launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s);
 }
 
+}  // namespace
+
+// The persistent ConvGRU kernels need all their workgroups (8 per group, one per CU) resident together.
+bool seq_persistent_ok(const rgp_grcn* g) {
+  int n_cu = 0;
+  return g->seq_groups > 0 && device_cu_count(&n_cu) == RGP_OK && g->seq_groups * 8 <= n_cu;
+}
+
+namespace {
+
 // All T steps in one persistent launch (convgru_seq.hip.h): recurrent filters resident in registers, state on chip.
 int seq_persistent(rgp_grcn* g, hipStream_t s) {
   const int B = g->B, T_ = g->T, S = g->S;
@@ -127,9 +137,6 @@ int seq_persistent(rgp_grcn* g, hipStream_t s) {
   p.cnt = (unsigned*)(g->ws + g->seq_cnt.off);
   p.B = B; p.T = T_; p.NC = g->seq_nc; p.ngroups = g->seq_groups; p.K = g->gzr.K;
   RGP_REQUIRE(g->gzr.K == 9 * S && g->gc.K == 9 * S && g->gzr.chunk_major == 0, "convgru_seq: unexpected filter packing");
-  int n_cu = 0;
-  RGP_TRY(device_cu_count(&n_cu));
-  RGP_REQUIRE(g->seq_groups * 8 <= n_cu, "convgru_seq: %d workgroups must be co-resident on %d CUs", g->seq_groups * 8, n_cu);
   if (g->seq_nc == 1) {
     RGP_TRY(ensure_dyn_smem((const void*)convgru_seq_kernel<4>, SEQ_SMEM));
     convgru_seq_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
@@ -144,7 +151,7 @@ int seq_persistent(rgp_grcn* g, hipStream_t s) {
 template <typename T>
 int seq_impl(rgp_grcn* g, hipStream_t s) {
   const int B = g->B, T_ = g->T, S = g->S;
-  if (sizeof(T) == 2 && g->seq_groups > 0 && dev_knob("RGP_SEQ", 1)) return seq_persistent(g, s);
+  if (sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1)) return seq_persistent(g, s);
   const size_t st = (size_t)B * 49 * S;  // fp32 elements per state snapshot
   RGP_HIP(hipMemsetAsync(g->ws + g->hp.off, 0, g->hp.bytes, s));      // h_0 = 0 (gaze_grcn.py:262)
   RGP_HIP(hipMemsetAsync(g->ws + g->hall.off, 0, st * 4, s));

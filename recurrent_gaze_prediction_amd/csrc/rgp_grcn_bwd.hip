@@ -176,7 +176,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
                                                   (float*)gr->bn_beta, Fp(b->dh_head), B, T_, S, inv);
   // 6. BPTT: t = T-1 .. 0 -- one persistent launch where the plan allows it (bf16, the reference cell, <= 64 clips)
   const int ew_blocks = (int)std::min<size_t>((st + 255) / 256, 4096);
-  const bool persistent = sizeof(T) == 2 && g->seq_groups > 0 && dev_knob("RGP_SEQ", 1);
+  const bool persistent = sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1);
   if (persistent) {
     RGP_HIP(hipMemsetAsync(ws + b->bptt_cnt.off, 0, b->bptt_cnt.bytes, s));      // phase counters: zeroed EVERY call
     BpttParams q;

@@ -34,6 +34,8 @@ inline Buf take(rgp::Arena& a, size_t bytes) {
   return b;
 }
 
+// rgp_grcn.hip: the persistent ConvGRU kernels apply to this plan on the current device
+bool seq_persistent_ok(const rgp_grcn* g);
 // rgp_grcn_bwd.hip
 int grcn_bwd_plan(rgp_grcn* g, rgp::Arena& a);
 int grcn_bwd_upload(rgp_grcn* g, hipStream_t s);

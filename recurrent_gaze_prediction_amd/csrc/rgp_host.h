@@ -230,8 +230,13 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
 #endif
         return launch_wide<256, 256, P, Epi>(p, e, s);
       }
-      if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024)
+      if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024) {
+#ifdef RGP_DEV_KNOBS
+        if (dev_knob("RGP_WVAR", 0) == 2) return launch_wide<512, 128, P, Epi, 2>(p, e, s);
+        if (dev_knob("RGP_WVAR", 0) == 3) return launch_wide<512, 128, P, Epi, 1>(p, e, s);
+#endif
         return launch_wide<512, 128, P, Epi>(p, e, s);
+      }
     }
   }
   if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)

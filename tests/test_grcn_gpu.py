@@ -84,3 +84,28 @@ def test_single_clip_single_step_edge(gpu):
     logits, probs = eng.forward(torch.tensor(x, device=gpu))
     assert rel_err(logits.cpu().numpy(), ref_logits) < TOL['f32']
     assert abs(probs.sum().item() - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize('B,T', [(3, 5), (33, 4), (64, 3), (1, 2)])
+def test_persistent_sequence_kernel_group_shapes(gpu, B, T):
+    """The persistent ConvGRU kernel (bf16, convgru_seq.hip.h) deals clips to groups of 8 workgroups: one clip per group
+    with a group count that is not a multiple of 8 (B = 3, plain group numbering), two clips per group with a ragged
+    last group (B = 33: 17 groups, the last one holds one clip), the full chip (B = 64: 32 groups) and a single group.
+    States of every step and logits against the float64 oracle, plus the batch-normalised head input."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    p = syn.grcn_params(31 + B, T, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(32 + B, B, T)
+    ref_logits, ref_h, _ = oracle_forward(x, p)
+    eng = GrcnEngine(B, T, dtype='bf16', device=gpu)
+    eng.set_weights(p)
+    logits, _ = eng.forward(torch.tensor(x, device=gpu))
+    h = eng.read_buffer('rcn_outputs').cpu().numpy().reshape(ref_h.shape)
+    assert np.isfinite(h).all()
+    assert rel_err(h, ref_h) < TOL_H_MAX['bf16']
+    for t in range(T):          # every step, every clip (a clip dealt to the wrong group would be O(1) off)
+        for b in (0, B // 2, B - 1):
+            assert rel_err(h[b, t], ref_h[b, t]) < TOL_H_MAX['bf16'], (b, t)
+    assert rel_err(logits.cpu().numpy(), ref_logits) < TOL['bf16']
+    # a second call on the same plan gives the same result (phase counters are re-zeroed per launch)
+    logits2, _ = eng.forward(torch.tensor(x, device=gpu))
+    assert torch.equal(logits, logits2)
