@@ -87,7 +87,7 @@ def grcn_step():
 
 out['cfg3_grcn_bf16_B64_T16_head_train_step'] = entry(B * T, timed(grcn_step))
 del eng
-c3d = C3DEngine(256, dtype='bf16', device=dev)
+c3d = C3DEngine(1024, dtype='bf16', device=dev)
 c3d.set_weights(syn.c3d_params(4))
 head = GrcnEngine(B, T, dtype='bf16', device=dev)
 head.set_weights(syn.grcn_params(3, T))
