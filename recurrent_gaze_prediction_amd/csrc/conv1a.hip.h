@@ -3,25 +3,41 @@
 //
 // conv1a has K = 81: far too short for the LDS-staged implicit-GEMM tile loop (three K-chunks per tile, so
 // tile set-up, barriers and the epilogue dominate), and its output (6.4 MB per window) is 5x its input, so the
-// kernel is organised around streaming:
+// kernel is organised around streaming, and -- the MFMA time of a tile being only 448 cycles -- around the number of
+// instructions a wave issues per tile (MI355X guide, 'vector-instruction ISSUE cost': every VALU / LDS / s_nop costs
+// 4 issue cycles of the SIMD, a 16x16x32 MFMA 8 of its 16, a 32x32x16 MFMA 8 of its 32):
 //
-//  * input  act0 [n][18][114][116][4] bf16 (halo-padded, channels 3->4, 8 bytes per pixel).
-//  * a block (4 waves) walks JOBS = (window, plane z, 4 pooled rows): the 3 x 10 x 116-pixel input patch of a job
-//    (27.2 KiB) is fetched ONCE, with coalesced 16-byte loads into registers while the previous job computes,
-//    and parked in LDS (double-buffered, one barrier per job).  The first version of this kernel built its
-//    A-fragments straight from global memory: every input pixel went through the texture path ~50 times
-//    (64 GB per 1024 windows at 64 B/clk/CU = as long as the MFMAs themselves) and the kernel ran at 31 %
-//    MFMA utilisation; fragments now come from LDS (two ds_read_b64 each).
-//  * K is ordered (kz,ky,kx | c4): 27 taps x 4 channels = 108, padded to 128 = 4 MFMA k-steps (was 160 = 5).
-//    A lane's 8-element A-fragment is two taps = two 8-byte pixels.
-//  * filter packed [64][128] bf16 -> 16 B-fragments (64 VGPRs) loaded once per wave.
-//  * wave tile = 32 conv rows = 8 pooled pixels x 64 channels, 28 tiles per job, 7 per wave.  Rows are ordered
-//    (pooling window, dy, dx), so the 4 rows of a window are the 4 accumulator registers of one lane
-//    (v_mfma_f32_16x16x32 C layout: row = 4*(lane>>4)+reg): pool1 is an in-lane max, then bias + ReLU.
-//  * the pooled 8x64 bf16 tile is transposed through 1 KiB of wave-private LDS so the store is one fully
-//    coalesced 1 KiB run (8 adjacent pixels x 128 B).
-//  * jobs are dealt to the 8 XCDs in contiguous ranges (consecutive workgroup ids sit on different XCDs), so
-//    the 3x plane overlap and the y halo between neighbouring jobs are served by one XCD's L2.
+//  * input  act0 [n][18][114][116][4] bf16 (halo-padded, channels 3->4, 8 bytes per pixel), or (FUSED) the caller's
+//    fp32 windows converted on the fly.
+//  * a block (4 waves) walks COLUMNS = (window, 4 pooled rows) through the 16 planes z: the input of a job (window, z,
+//    4 pooled rows) is 3 planes x 10 rows x 116 pixels, and consecutive z share two of the three planes, so LDS holds
+//    a ring of 4 plane slabs: every job fetches ONE new slab (10 rows, with coalesced 16-byte loads into registers
+//    while the current job computes; one barrier per job).  Round 1's kernel fetched all three planes for every job
+//    and left the overlap to L2, which the 6.4 MB / window of output streaming through it evicts: FETCH_SIZE was
+//    2.2x the input.
+//  * slab rows have a pitch of 144 pixel slots = 1152 B = 128 (mod 256): the two image rows a fragment read touches
+//    (16 pixels = 128 B each) fall on disjoint halves of the 64 banks.
+//  * K is ordered (kz,ky,kx | c4): 27 taps x 4 channels = 108, padded to 112 = 7 k-steps of v_mfma_f32_32x32x16_bf16
+//    (round 1: 128 = 4 steps of 16x16x32, twice the MFMA instructions for the same rows).  A lane's 8-element
+//    A-fragment is two taps = two 8-byte pixels = two ds_read_b64.
+//  * bias and ReLU ride in the GEMM: the 4th channel of every parked pixel is 1.0, the 4th-channel weight of the
+//    centre tap is bf16(bias) and that of the padding tap 27 -- which reads the centre pixel again -- is the bf16
+//    remainder (bias to 2^-17 relative); ReLU is the 0 in the second max3 of the pooling.
+//  * filter [64][128] bf16 -> 14 B-fragments (56 VGPRs) loaded once per wave.
+//  * wave tile = 32 conv rows = 8 pooled pixels x 64 channels; wave w of a block owns pooled row w of the job and walks
+//    its 7 tiles in x, so every fragment read is (one per-lane base VGPR) + (compile-time offset).  Rows are ordered
+//    (pooling window, dy, dx), so the 4 rows of a window are 4 consecutive accumulator registers of one lane
+//    (32x32 C layout: row = (reg&3) + 8 (reg>>2) + 4 (lane>>5)): pool1 + ReLU = two v_max3_f32 per value.
+//  * MFMA column c of n-tile nt carries output channel 2c + nt (the filter fragments are loaded in that order), so a
+//    lane ends a tile with 2 ADJACENT channels of 4 pooled pixels: the store is one dword per lane straight from
+//    registers, 32 lanes = one pixel's 128 B, the wave = 256 contiguous bytes -- no LDS transpose.
+//  * the fragment reads are inline asm: left to itself the compiler fuses pairs of them into ds_read2_b64, which
+//    banks mod 32 and takes 8 LDS cycles where two ds_read_b64 take 4 (round 1's kernel: 50 % of its LDS cycles were
+//    bank conflicts).
+//  * this translation unit is compiled with -fno-honor-nans: fmaxf() on MFMA results otherwise costs a quieting
+//    v_max_f32 x, x per operand under the IEEE mode (5 instructions per pooled value instead of 2).
+//  * columns are dealt to the 8 XCDs in contiguous ranges (consecutive workgroup ids sit on different XCDs), so the
+//    y halo between neighbouring columns is served by one XCD's L2.
 #pragma once
 #include "igemm.hip.h"
 
@@ -30,7 +46,7 @@ namespace rgp {
 struct Conv1aParams {
   const float* video;   // FUSED variant: the caller's mean-subtracted clip windows [n][16][112][112][3] fp32, read directly
                         // (the separate video_prep pass -- 2.4 MB read + 1.9 MB written per window, 0.93 ms per 1024
-                        // windows at HBM rate -- is folded into the patch fetch)
+                        // windows at HBM rate -- is folded into the slab fetch)
   const bf16_t* in;     // [n][18][114][116][4]
   const bf16_t* wp;     // [64][128]
   const float* bias;    // [64]
@@ -40,243 +56,295 @@ struct Conv1aParams {
 };
 
 constexpr int C1_D = 16, C1_H = 112, C1_HP = 114, C1_WP = 116, C1_K = 128;
+constexpr int C1_KSTEPS = 7;                    // 7 x 16 = 112 >= 27 taps x 4
 constexpr int C1_PO = 56;                       // pooled extent
 constexpr int C1_XG = C1_PO / 8;                // 8 pooled pixels per wave tile
 constexpr int C1_OUT_P = 58;
 constexpr int C1_JROWS = 4;                     // pooled rows per job
-constexpr int C1_YQ = C1_PO / C1_JROWS;         // 14 jobs per plane
-constexpr int C1_JOBS_PER_WINDOW = C1_D * C1_YQ;
-constexpr int C1_PROWS = 2 * C1_JROWS + 2;      // 10 input rows per plane of a patch
-constexpr int C1_ROWB = C1_WP * 8;              // 928 bytes per input row
-constexpr int C1_PATCH = 3 * C1_PROWS * C1_ROWB;          // 27840 bytes
-constexpr int C1_CHUNKS = C1_PATCH / 16;                  // 1740 16-byte chunks
-constexpr int C1_CPR = C1_ROWB / 16;                      // 58 chunks per row
-constexpr int C1_NLD = (C1_CHUNKS + 255) / 256;           // 7 loads per thread
-constexpr int C1_TILES = C1_JROWS * C1_XG;                // 28 wave tiles per job
-constexpr int C1_SMEM = 2 * C1_PATCH + 4 * 8 * 72 * 2 + 4 * 8 * 72;
-// FUSED variant: LDS patch rows of 118 pixel slots (944 B): slot 1 = x -1 (zero), slots 2..113 = x 0..111, so that the
-// 4-pixel groups converted from fp32 land on 16-byte boundaries; slots 0, 1 and 114..117 stay zero for the whole kernel
-constexpr int C1F_WPL = 118;
-constexpr int C1F_PATCH = 3 * C1_PROWS * C1F_WPL * 8;     // 28 320 bytes
-constexpr int C1F_GROUPS = 3 * C1_PROWS * 28;             // 840 groups of 4 pixels (12 floats = three 16-byte loads)
-constexpr int C1F_NLD = (C1F_GROUPS + 255) / 256;         // 4 per thread
-constexpr int C1F_SMEM = 2 * C1F_PATCH + 4 * 8 * 72 * 2 + 4 * 8 * 72;
+constexpr int C1_YQ = C1_PO / C1_JROWS;         // 14 columns per window
+constexpr int C1_PROWS = 2 * C1_JROWS + 2;      // 10 input rows per slab
+constexpr int C1_ROWB = C1_WP * 8;              // 928 bytes per act0 row
+constexpr int C1_WPL = 144;                     // LDS slab row pitch in pixel slots (1152 B)
+constexpr int C1_SLAB = C1_PROWS * C1_WPL * 8;  // 11 520 bytes
+constexpr int C1_SMEM = 4 * C1_SLAB;            // ring of 4 slabs
+constexpr int C1_STREAM = C1_D + 2;             // slabs per column: planes -1 .. 16
+// act0 variant: a slab row = the 116 pixels of an act0 row (slot 0 = x -1) = 58 16-byte chunks
+constexpr int C1_CPR = C1_WP * 8 / 16;                    // 58 chunks per row
+constexpr int C1_CHUNKS = C1_PROWS * C1_CPR;              // 580
+constexpr int C1_NLD = (C1_CHUNKS + 255) / 256;           // 3 loads per thread
+// FUSED variant: slot 1 = x -1 (zero), slots 2..113 = x 0..111, so that the 4-pixel groups converted from fp32 land
+// on 16-byte boundaries; every slot the fetch does not write stays zero for the whole kernel
+constexpr int C1F_GROUPS = C1_PROWS * 28;                 // 280 groups of 4 pixels (12 floats = three 16-byte loads)
+constexpr int C1F_NLD = (C1F_GROUPS + 255) / 256;         // 2 per thread
 
-template <bool FUSED>
+template <int V> struct C1Int { static constexpr int value = V; };
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8_c1 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int OFF>
+static __device__ __forceinline__ u32x2 c1_lds_read64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// all LDS reads issued so far have landed; the fragments pass through the statement so that no use is scheduled above it
+static __device__ __forceinline__ void c1_lds_wait(u32x2 (&a)[C1_KSTEPS][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
+                 "+v"(a[3][1]), "+v"(a[4][0]), "+v"(a[4][1]), "+v"(a[5][0]), "+v"(a[5][1]), "+v"(a[6][0]), "+v"(a[6][1]));
+}
+static constexpr __host__ __device__ int c1_tap_kz(int tap) { return (tap > 26 ? 13 : tap) / 9; }
+
+// VAR (dev builds only): 2 = no output stores, 4 = no slab fetch after the first (timing ablations)
+template <bool FUSED, bool ARGMAX, int VAR = 0>
 static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const Conv1aParams p) {
-  constexpr int WPL = FUSED ? C1F_WPL : C1_WP;             // LDS patch row pitch in pixel slots
+  constexpr int WPL = C1_WPL;
   constexpr int XS = FUSED ? 1 : 0;                        // slot of x = -1
-  constexpr int PATCH = FUSED ? C1F_PATCH : C1_PATCH;
   extern __shared__ __attribute__((aligned(16))) char c1_smem[];
-  char* patch = c1_smem;                                                   // [2][PATCH]
-  bf16_t* s_out = (bf16_t*)(c1_smem + 2 * PATCH);                          // per wave: 8 px x (64 ch + 8 pad)
-  unsigned char* s_arg = (unsigned char*)(s_out + 4 * 8 * 72);
-  if constexpr (FUSED) {      // the x-halo slots are never written afterwards
-    for (int i = threadIdx.x; i < 2 * PATCH / 16; i += 256) ((u32x4*)patch)[i] = (u32x4){0u, 0u, 0u, 0u};
-    __syncthreads();
-  }
+  char* ring = c1_smem;                                                    // [4][C1_SLAB]
+  for (int i = threadIdx.x; i < C1_SMEM / 16; i += 256) ((u32x4*)ring)[i] = (u32x4){0u, 0u, 0u, 0u};
+  __syncthreads();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int frow = lane & 15, kg = lane >> 4;
+  const int frow = lane & 31, kh = lane >> 5;
 
-  // jobs of this block: XCD x owns the contiguous range [x*per_xcd, (x+1)*per_xcd)
-  const long long total = (long long)p.n_windows * C1_JOBS_PER_WINDOW;
+  // columns of this block: XCD x owns the contiguous range [x*per_xcd, (x+1)*per_xcd)
+  const long long total = (long long)p.n_windows * C1_YQ;
   const long long per_xcd = (total + 7) / 8;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-  long long job = xcd * per_xcd + slot;
-  long long job_end = (xcd + 1) * per_xcd;
-  if (job_end > total) job_end = total;
-  if (job >= job_end) return;
+  long long col = xcd * per_xcd + slot;
+  long long col_end = (xcd + 1) * per_xcd;
+  if (col_end > total) col_end = total;
+  if (col >= col_end) return;
 
-  // filter fragments: B[k = 32s + 8kg + j][n = 16jn + frow]
-  f32x4 bfrag[4][4];
+  // filter fragments: B[k = 16s + 8kh + j][MFMA column frow of n-tile nt = output channel 2 frow + nt]; the bias
+  // goes into the 4th-channel slots of the centre tap (k = 55: s 3, kh 0, j 7) and of tap 27 (k = 111: s 6, kh 1, j 7)
+  u32x4 bfrag[C1_KSTEPS][2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < C1_KSTEPS; ++s)
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-      bfrag[s][jn] = *(const f32x4*)(p.wp + (jn * 16 + frow) * C1_K + s * 32 + kg * 8);
-  float bias_v[4];
+    for (int nt = 0; nt < 2; ++nt)
+      bfrag[s][nt] = *(const u32x4*)(p.wp + (frow * 2 + nt) * C1_K + s * 16 + kh * 8);
 #pragma unroll
-  for (int jn = 0; jn < 4; ++jn) bias_v[jn] = p.bias[jn * 16 + frow];
+  for (int nt = 0; nt < 2; ++nt) {
+    const float b = p.bias[frow * 2 + nt];
+    const bf16_t hi = f2bf(b);
+    const bf16_t lo = f2bf(b - bf2f(hi));
+    if (kh == 0) bfrag[3][nt][3] = (bfrag[3][nt][3] & 0xffffu) | ((unsigned)hi << 16);
+    else bfrag[6][nt][3] = (bfrag[6][nt][3] & 0xffffu) | ((unsigned)lo << 16);
+  }
 
-  // patch chunk q = tid + 256 u: where it comes from (elements, relative to the job's first row) and valid?
-  int g_off[C1_NLD];
+  // ---- slab fetch: stream position (column c = (window n, row quarter yq), plane pz = z + 1 in 0..17) ----
+  // act0 variant: slab chunk q = tid + 256 u: where it comes from (elements, relative to the slab's first row) and
+  // where it goes in the slab (bytes)
+  int g_off[C1_NLD], l_off[C1_NLD];
 #pragma unroll
   for (int u = 0; u < C1_NLD; ++u) {
     int q = tid + 256 * u;
     if (q >= C1_CHUNKS) q = C1_CHUNKS - 1;                 // duplicate, never written
-    const int row = q / C1_CPR, c = q - row * C1_CPR;
-    const int kz = row / C1_PROWS, ry = row - kz * C1_PROWS;
-    g_off[u] = ((kz * C1_HP + ry) * C1_WP) * 4 + c * 8;
+    const int ry = q / C1_CPR, c = q - ry * C1_CPR;
+    g_off[u] = (ry * C1_WP) * 4 + c * 8;
+    l_off[u] = ry * (WPL * 8) + c * 16;
   }
-  auto job_src = [&](long long j) -> const bf16_t* {
-    const int yq = (int)(j % C1_YQ);
-    const int z = (int)((j / C1_YQ) % C1_D);
-    const long long n = j / C1_JOBS_PER_WINDOW;
-    return p.in + (((n * (C1_D + 2) + z) * C1_HP + yq * 2 * C1_JROWS) * (long long)C1_WP) * 4;
-  };
-  auto fetch = [&](long long j, u32x4 (&pf)[C1_NLD]) {
-    const bf16_t* src = job_src(j);
+  auto fetch = [&](long long c, int pz, u32x4 (&pf)[C1_NLD]) {
+    const int yq = (int)(c % C1_YQ);
+    const long long n = c / C1_YQ;
+    const bf16_t* src = p.in + (((n * (C1_D + 2) + pz) * C1_HP + yq * 2 * C1_JROWS) * (long long)C1_WP) * 4;
 #pragma unroll
     for (int u = 0; u < C1_NLD; ++u) pf[u] = *(const u32x4*)(src + g_off[u]);
   };
-  auto park = [&](char* buf, const u32x4 (&pf)[C1_NLD]) {
+  auto park = [&](char* slab, const u32x4 (&pf)[C1_NLD]) {
 #pragma unroll
     for (int u = 0; u < C1_NLD; ++u)
-      if (tid + 256 * u < C1_CHUNKS) *(u32x4*)(buf + (tid + 256 * u) * 16) = pf[u];
+      if (tid + 256 * u < C1_CHUNKS) {
+        u32x4 v = pf[u];
+        v[1] |= 0x3f800000u;                               // 4th channel = 1.0 (act0 carries 0 there)
+        v[3] |= 0x3f800000u;
+        *(u32x4*)(slab + l_off[u]) = v;
+      }
   };
-  // FUSED: group q = tid + 256 u of the patch = row q / 28 (plane kz = row / 10, row ry = row % 10), pixels 4 (q % 28)..+3
-  // -> three 16-byte loads of 12 floats from the fp32 window; rows / planes outside the window give zeros
-  // (row / group are recomputed from tid where needed: 8 fewer live VGPRs in a kernel at the 256-register limit)
-  auto grp = [&](int u, int& row, int& xg) {
+  // FUSED: group q = tid + 256 u of the slab = row ry = q / 28, pixels 4 (q % 28)..+3 -> three 16-byte loads of 12
+  // floats from the fp32 window.  The loads are buffer loads on the window (num_records = one window); planes -1 and
+  // 16 and the image rows -1 and 112 (first / last column of a window) get an out-of-range offset -> zeros.
+  constexpr unsigned WIN_BYTES = C1_D * C1_H * C1_H * 12u;
+  unsigned f_src[C1F_NLD], f_dst[C1F_NLD], f_edge = 0;     // edge bits: u -> group is slab row 0, 4+u -> slab row 9
+#pragma unroll
+  for (int u = 0; u < C1F_NLD; ++u) {
     int q = tid + 256 * u;
     if (q >= C1F_GROUPS) q = C1F_GROUPS - 1;                 // duplicate, never written
-    row = (q * 2341) >> 16;                                  // q / 28 for q < 840
-    xg = q - row * 28;
-  };
-  auto fetch_f = [&](long long j, f32x4 (&pf)[C1F_NLD][3]) {
-    const int yq = (int)(j % C1_YQ);
-    const int z = (int)((j / C1_YQ) % C1_D);
-    const long long n = j / C1_JOBS_PER_WINDOW;
+    const int ry = q / 28, xg = q - ry * 28;
+    f_src[u] = (unsigned)((ry * C1_H + 4 * xg) * 12);
+    f_dst[u] = (unsigned)((ry * WPL + 2 + 4 * xg) * 8);
+    if (ry == 0) f_edge |= 1u << u;
+    if (ry == C1_PROWS - 1) f_edge |= 16u << u;
+  }
+  auto fetch_f = [&](long long c, int pz, f32x4 (&pf)[C1F_NLD][3]) {
+    const int yq = (int)(c % C1_YQ);
+    const long long n = c / C1_YQ;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.video + n * (long long)(WIN_BYTES / 4)), 0,
+                                                        WIN_BYTES, 0x00020000);
+    const bool plane_ok = pz >= 1 && pz <= C1_D;
+    const unsigned job_off = (unsigned)((((pz - 1) * C1_H + yq * 2 * C1_JROWS - 1) * C1_H) * 12);
+    const unsigned edge = plane_ok ? f_edge & ((yq == 0 ? 0xfu : 0u) | (yq == C1_YQ - 1 ? 0xf0u : 0u)) : 0xffu;
 #pragma unroll
     for (int u = 0; u < C1F_NLD; ++u) {
-      int row, xg;
-      grp(u, row, xg);
-      const int kz = row / C1_PROWS, ry = row - kz * C1_PROWS;
-      const int zz = z + kz - 1, yy = yq * 2 * C1_JROWS + ry - 1;
-      const bool ok = zz >= 0 && zz < C1_D && yy >= 0 && yy < C1_H;
-      const float* src = p.video + (((n * C1_D + (ok ? zz : 0)) * C1_H + (ok ? yy : 0)) * (long long)C1_H + 4 * xg) * 3;
+      const unsigned off = (edge & (0x11u << u)) ? 0x80000000u : f_src[u] + job_off;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pf[u][k] = ok ? *(const f32x4*)(src + 4 * k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 3; ++k)
+        pf[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * k, 0, 0));
     }
   };
-  auto park_f = [&](char* buf, const f32x4 (&pf)[C1F_NLD][3]) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  auto pk = [](float x, float y) -> unsigned {               // v_cvt_pk_bf16_f32
+    const f32x2_t v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  };
+  auto park_f = [&](char* slab, const f32x4 (&pf)[C1F_NLD][3]) {
 #pragma unroll
     for (int u = 0; u < C1F_NLD; ++u) {
       if (tid + 256 * u < C1F_GROUPS) {
         const float f[12] = {pf[u][0][0], pf[u][0][1], pf[u][0][2], pf[u][0][3], pf[u][1][0], pf[u][1][1],
                              pf[u][1][2], pf[u][1][3], pf[u][2][0], pf[u][2][1], pf[u][2][2], pf[u][2][3]};
-        // two packed conversions per pixel (v_cvt_pk_bf16_f32): {c0, c1}, {c2, 0}
-        typedef float f32x2_ __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        // two packed conversions per pixel: {c0, c1}, {c2, 1.0}
         u32x4 w0, w1;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-          const f32x2_ a = {f[3 * px], f[3 * px + 1]}, b = {f[3 * px + 2], 0.f};
-          const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_));
-          const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_));
+          const unsigned lo = pk(f[3 * px], f[3 * px + 1]), hi = pk(f[3 * px + 2], 1.f);
           if (px < 2) { w0[2 * px] = lo; w0[2 * px + 1] = hi; } else { w1[2 * (px - 2)] = lo; w1[2 * (px - 2) + 1] = hi; }
         }
-        int row, xg;
-        grp(u, row, xg);
-        char* dst = buf + (row * WPL + 2 + 4 * xg) * 8;
+        char* dst = slab + f_dst[u];
         *(u32x4*)dst = w0;
         *(u32x4*)(dst + 16) = w1;
       }
     }
   };
 
-  // per-lane fragment addressing inside a patch (bytes).  Row r of an m-tile: window w = frow>>2,
-  // dy = (frow>>1)&1, dx = frow&1; K-chunk 4s+kg = taps 2(4s+kg), 2(4s+kg)+1 (taps >= 27 carry zero weights).
+  // ---- fragment addressing (bytes).  Row m = frow of the tile: window w = m>>2, dy = (m>>1)&1, dx = m&1; k-step s,
+  // half kh = taps 4s + 2kh, 4s + 2kh + 1 (tap 27 = the centre pixel again, for the bias remainder).  ra0: offset
+  // inside a slab; the slab of tap plane kz rotates with the job (ring), added per job.
   const int r_w = frow >> 2, r_dy = (frow >> 1) & 1, r_dx = frow & 1;
-  const int lane_base = (r_dy * WPL + 2 * r_w + r_dx + XS) * 8;
-  int toff[4][2];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)c1_smem;
+  const unsigned lane_base = lds0 + ((r_dy + 2 * wave) * WPL + 2 * r_w + r_dx + XS) * 8;
+  unsigned ra0[C1_KSTEPS][2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < C1_KSTEPS; ++s)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int tap = 2 * (4 * s + kg) + j;
-      if (tap > 26) tap = 0;
-      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-      toff[s][j] = ((kz * C1_PROWS + ky) * WPL + kx) * 8 + lane_base;
+      int tap = 4 * s + 2 * kh + j;
+      if (tap > 26) tap = 13;
+      const int ky = (tap / 3) % 3, kx = tap % 3;
+      ra0[s][j] = (ky * WPL + kx) * 8 + lane_base;
     }
 
-  auto load_frags = [&](const char* buf, int tile, f32x4 (&a)[2][4]) {
-    const int yl = tile / C1_XG, xg = tile - yl * C1_XG;
-    const char* tb = buf + (2 * yl * WPL + 16 * xg) * 8;
+  // fragments of tile OFF / 128 of this wave's row; c1_lds_wait() before the first use
+  auto load_frags = [&](auto OFF, const unsigned (&ra)[C1_KSTEPS][2], u32x2 (&a)[C1_KSTEPS][2]) {
+    constexpr int off = decltype(OFF)::value;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int s = 0; s < C1_KSTEPS; ++s)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const uint2 lo = *(const uint2*)(tb + mi * 64 + toff[s][0]);
-        const uint2 hi = *(const uint2*)(tb + mi * 64 + toff[s][1]);
-        const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
-        a[mi][s] = __builtin_bit_cast(f32x4, v);
-      }
+      for (int j = 0; j < 2; ++j) a[s][j] = c1_lds_read64<off>(ra[s][j]);
   };
-  auto process = [&](long long j, int tile, const f32x4 (&a)[2][4]) {
-    f32x4 acc[2][4];
+  // this lane's part of the output address: pixel kh of a pixel pair, channels 2 frow, 2 frow + 1
+  const int o_lane = kh * 64 + frow * 2;
+  auto tile = [&](bf16_t* orow, unsigned char* arow, int xg, const u32x2 (&a)[C1_KSTEPS][2]) {
+    f32x16 acc[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int jn = 0; jn < 4; ++jn) acc[mi][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < C1_KSTEPS; ++s) {
+      const u32x4 av = {a[s][0][0], a[s][0][1], a[s][1][0], a[s][1][1]};
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8_c1, av),
+                                                          __builtin_bit_cast(s16x8_c1, bfrag[s][nt]), acc[nt], 0, 0, 0);
+    }
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn) Mma<bf16_t>::step(acc[mi][jn], a[mi][s], bfrag[s][jn]);
-    bf16_t* so = s_out + wave * 8 * 72;
-    unsigned char* sa = s_arg + wave * 8 * 72;
+    for (int j = 0; j < 4; ++j) {                            // pooled pixel 2j + kh of the tile
+      float v[2];
+      unsigned codes = 0;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) {
-        const f32x4 c = acc[mi][jn];
-        const float v = fmaxf(fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])) + bias_v[jn], 0.f);   // pool1, bias, ReLU
-        so[(mi * 4 + kg) * 72 + jn * 16 + frow] = f2bf(v);
-        if (p.argmax) {
-          float best = c[0];
-          unsigned char idx = 0;
-#pragma unroll
-          for (int r = 1; r < 4; ++r)
-            if (c[r] > best) { best = c[r]; idx = (unsigned char)r; }
-          sa[(mi * 4 + kg) * 72 + jn * 16 + frow] = idx;
+      for (int nt = 0; nt < 2; ++nt) {
+        const float c0 = acc[nt][4 * j], c1 = acc[nt][4 * j + 1], c2 = acc[nt][4 * j + 2], c3 = acc[nt][4 * j + 3];
+        v[nt] = fmaxf(fmaxf(fmaxf(fmaxf(c0, c1), c2), c3), 0.f);      // pool1 + ReLU (the bias is in the sums): 2 v_max3_f32
+        if constexpr (ARGMAX) {
+          float best = c0;
+          unsigned idx = 0;
+          if (c1 > best) { best = c1; idx = 1; }
+          if (c2 > best) { best = c2; idx = 2; }
+          if (c3 > best) { best = c3; idx = 3; }
+          codes |= idx << (8 * nt);
         }
       }
-    __builtin_amdgcn_wave_barrier();   // wave-private LDS: DS ops of one wave execute in order
-    const int px = lane >> 3, chunk = lane & 7;
-    const u32x4 row = *(const u32x4*)(so + px * 72 + chunk * 8);
-    const int yl = tile / C1_XG, xg = tile - yl * C1_XG;
-    const int yo = (int)(j % C1_YQ) * C1_JROWS + yl;
-    const int z = (int)((j / C1_YQ) % C1_D);
-    const long long n = j / C1_JOBS_PER_WINDOW;
-    const long long o = (((n * (C1_D + 2) + z + 1) * C1_OUT_P + yo + 1) * (long long)C1_OUT_P + xg * 8 + px + 1) * 64 + chunk * 8;
-    *(u32x4*)(p.out + o) = row;
-    if (p.argmax) {
-      const uint2 codes = *(const uint2*)(sa + px * 72 + chunk * 8);
-      const long long oa = (((n * C1_D + z) * C1_PO + yo) * (long long)C1_PO + xg * 8 + px) * 64 + chunk * 8;
-      *(uint2*)(p.argmax + oa) = codes;
+      if (!(VAR & 2) || p.n_windows < 0) *(unsigned*)(orow + (xg * 8 + 2 * j) * 64 + o_lane) = pk(v[0], v[1]);
+      if constexpr (ARGMAX) *(unsigned short*)(arow + (xg * 8 + 2 * j) * 64 + o_lane) = (unsigned short)codes;
     }
-    __builtin_amdgcn_wave_barrier();
+  };
+  // job (column c, plane z) with tap plane kz in ring slab (rb + kz) & 3: this wave's pooled row, 7 tiles, fragments
+  // of tile i+1 in flight under tile i.  (Measured and not kept: tile i's pooling issued behind tile i+1's MFMAs with two
+  // accumulator sets, +10 %; three blocks per CU at 168 registers, +30 %; non-temporal stores, +-0.)
+  auto compute = [&](long long c, int z, int rb) {
+    const unsigned so[3] = {(unsigned)(rb & 3) * C1_SLAB, (unsigned)((rb + 1) & 3) * C1_SLAB, (unsigned)((rb + 2) & 3) * C1_SLAB};
+    unsigned ra[C1_KSTEPS][2];
+#pragma unroll
+    for (int s = 0; s < C1_KSTEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ra[s][j] = ra0[s][j] + (kh ? so[c1_tap_kz(4 * s + 2 + j)] : so[c1_tap_kz(4 * s + j)]);
+    const int yo = (int)(c % C1_YQ) * C1_JROWS + wave;
+    const long long n = c / C1_YQ;
+    bf16_t* orow = p.out + (((n * (C1_D + 2) + z + 1) * C1_OUT_P + yo + 1) * (long long)C1_OUT_P + 1) * 64;
+    unsigned char* arow = ARGMAX ? p.argmax + (((n * C1_D + z) * C1_PO + yo) * (long long)C1_PO) * 64 : nullptr;
+    u32x2 a0[C1_KSTEPS][2], a1[C1_KSTEPS][2];
+    load_frags(C1Int<0>{}, ra, a0);
+    c1_lds_wait(a0);
+    load_frags(C1Int<128>{}, ra, a1);
+    tile(orow, arow, 0, a0);
+    c1_lds_wait(a1);
+    load_frags(C1Int<256>{}, ra, a0);
+    tile(orow, arow, 1, a1);
+    c1_lds_wait(a0);
+    load_frags(C1Int<384>{}, ra, a1);
+    tile(orow, arow, 2, a0);
+    c1_lds_wait(a1);
+    load_frags(C1Int<512>{}, ra, a0);
+    tile(orow, arow, 3, a1);
+    c1_lds_wait(a0);
+    load_frags(C1Int<640>{}, ra, a1);
+    tile(orow, arow, 4, a0);
+    c1_lds_wait(a1);
+    load_frags(C1Int<768>{}, ra, a0);
+    tile(orow, arow, 5, a1);
+    c1_lds_wait(a0);
+    tile(orow, arow, 6, a0);
   };
 
+  // ---- the slab stream: position i of this block = (column, plane pz) lives in ring slab i & 3; the job of plane
+  // z = pz - 2 runs once slab i is parked, on slabs i-2, i-1, i, while slab i+1 is in flight in registers; it is parked
+  // into slab (i+1) & 3 = (i-3) & 3, last read by the previous job, which every wave has left (the barrier).
   u32x4 pf[C1_NLD];
   f32x4 pff[C1F_NLD][3];
-  if constexpr (FUSED) { fetch_f(job, pff); park_f(patch, pff); }
-  else { fetch(job, pf); park(patch, pf); }
+  int pz = 0, i = 0;
+  if constexpr (FUSED) { fetch_f(col, 0, pff); park_f(ring, pff); }
+  else { fetch(col, 0, pf); park(ring, pf); }
   __syncthreads();
-  int cur = 0;
   while (true) {
-    const long long nxt = job + nslot;
-    const bool more = nxt < job_end;
-    if (more) {                                     // in flight while this job's 7 tiles per wave compute
-      if constexpr (FUSED) fetch_f(nxt, pff); else fetch(nxt, pf);
-    }
-    const char* buf = patch + cur * PATCH;
-    f32x4 a[2][2][4];
-    load_frags(buf, wave, a[0]);
-#pragma unroll
-    for (int i = 0; i < C1_TILES / 4; ++i) {
-      if (i + 1 < C1_TILES / 4) load_frags(buf, wave + 4 * (i + 1), a[(i + 1) & 1]);
-      process(job, wave + 4 * i, a[i & 1]);
-    }
+    const bool wrap = pz == C1_STREAM - 1;
+    const long long ncol = wrap ? col + nslot : col;
+    const int npz = wrap ? 0 : pz + 1;
+    const bool more = ncol < col_end;
+    if (more && (!(VAR & 4) || i < 4)) { if constexpr (FUSED) fetch_f(ncol, npz, pff); else fetch(ncol, npz, pf); }
+    if (pz >= 2) compute(col, pz - 2, i - 2);
     if (!more) break;
-    if constexpr (FUSED) park_f(patch + (cur ^ 1) * PATCH, pff); else park(patch + (cur ^ 1) * PATCH, pf);
-    __syncthreads();                                // next patch visible; everybody is done with this one
-    cur ^= 1;
-    job = nxt;
+    char* slab = ring + ((i + 1) & 3) * C1_SLAB;
+    if constexpr (FUSED) park_f(slab, pff); else park(slab, pf);
+    __syncthreads();                                // the new slab is visible; everybody is done with the oldest one
+    ++i;
+    col = ncol;
+    pz = npz;
   }
 }
 

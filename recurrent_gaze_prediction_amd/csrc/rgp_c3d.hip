@@ -5,7 +5,7 @@
 #include <algorithm>
 
 #include "rgp_c3d_plan.h"
-#include "conv1a.hip.h"
+#include "conv1a.hip.h"   // layout constants (C1_K)
 
 using namespace rgp;
 
@@ -41,23 +41,6 @@ int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
   }
 #endif
   return launch_igemm<T, G, P, EpiStore<T, true, true>>(p, e, s);
-}
-
-// bf16 conv1a: dedicated register-resident-filter kernel (conv1a.hip.h)
-int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video = nullptr) {
-  Conv1aParams p;
-  p.video = video;
-  p.in = (const bf16_t*)(c->ws + c->act_off[0]);
-  p.wp = (const bf16_t*)(c->ws + c->L[0].w_off);
-  p.bias = c->bias[0];
-  p.out = (bf16_t*)(c->ws + c->act_off[1]);
-  p.argmax = c->save ? (unsigned char*)(c->ws + c->B[0].argmax_off) : nullptr;
-  p.n_windows = n;
-  // two 4-wave blocks per CU, a multiple of 8 so that every XCD gets the same number of job slots
-  if (video) conv1a_pool_bf16_kernel<true><<<512, 256, C1F_SMEM, s>>>(p);      // reads the fp32 windows directly
-  else conv1a_pool_bf16_kernel<false><<<512, 256, C1_SMEM, s>>>(p);
-  RGP_HIP(hipGetLastError());
-  return RGP_OK;
 }
 
 template <typename T>
