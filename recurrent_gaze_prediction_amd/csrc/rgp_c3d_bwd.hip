@@ -146,7 +146,6 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       {
         const int Hp = l.H + 2, Wp = l.H + 2, Cx = i == 0 ? 4 : l.cin, Wpx = i == 0 ? l.H + 4 : l.H + 2;
         p.D = l.D; p.H = l.H; p.W = l.H;
-        p.inv_D = 1.0f / l.D; p.inv_H = 1.0f / l.H; p.inv_W = 1.0f / l.H;
         p.x_sx = Cx; p.x_sy = Wpx * Cx; p.x_sz = Hp * Wpx * Cx;
         p.y_sx = l.cout; p.y_sy = Wp * l.cout; p.y_sz = Hp * Wp * l.cout;
         p.y_org = p.y_sz + p.y_sy + p.y_sx;

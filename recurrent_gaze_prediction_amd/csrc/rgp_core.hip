@@ -1,4 +1,6 @@
 // librgp_hip.so: error reporting, device info, softmax / cross-entropy entry point.
+#include <array>
+#include <map>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -38,6 +40,54 @@ int device_cu_count(int* n_cu) {
 }
 
 thread_local char g_err[512] = "";
+
+namespace {
+__global__ void wgrad_row_tables_kernel(WgradGeom g, int n, int* __restrict__ xt, int* __restrict__ yt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int Mw = g.D * g.H * g.W;
+  const long long img = e / Mw;
+  int ml = e - (int)img * Mw;
+  const int x = ml % g.W;
+  ml /= g.W;
+  const int y = ml % g.H, z = ml / g.H;
+  xt[e] = (int)((img * g.x_img_stride + (long long)z * g.x_sz + (long long)y * g.x_sy + (long long)x * g.x_sx) * g.esz);
+  yt[e] = (int)((img * g.y_img_stride + g.y_org + (long long)z * g.y_sz + (long long)y * g.y_sy + (long long)x * g.y_sx) * g.esz);
+}
+}  // namespace
+
+int wgrad_row_tables(const WgradGeom& g, hipStream_t s, const int** x_tab, const int** y_tab) {
+  typedef std::array<long long, 15> Key;
+  static std::mutex mu;
+  static std::map<Key, std::pair<int*, int*>> cache;
+  int dev = 0;
+  RGP_HIP(hipGetDevice(&dev));
+  const Key key = {dev, g.D, g.H, g.W, g.x_sz, g.x_sy, g.x_sx, g.y_sz, g.y_sy, g.y_sx, g.y_org, g.esz, g.x_img_stride, g.y_img_stride, 0};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    const long long Mw = (long long)g.D * g.H * g.W;
+    if (Mw <= 0 || Mw > (1 << 28)) return set_err(RGP_EINVAL, "wgrad: bad grid %d x %d x %d", g.D, g.H, g.W);
+    const long long n = Mw + 32, imgs = (n + Mw - 1) / Mw;
+    const long long span_x = (imgs * g.x_img_stride + (long long)g.D * g.x_sz) * g.esz;
+    const long long span_y = (imgs * g.y_img_stride + g.y_org + (long long)g.D * g.y_sz) * g.esz;
+    if (span_x >= (1LL << 31) || span_y >= (1LL << 31) || span_x < 0 || span_y < 0)
+      return set_err(RGP_EINVAL, "wgrad: image too large for 32-bit row offsets");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    RGP_HIP(hipStreamIsCapturing(s, &cs));
+    if (cs != hipStreamCaptureStatusNone)
+      return set_err(RGP_EINVAL, "wgrad: first use of a geometry inside a stream capture (run one step eagerly first)");
+    int* buf = nullptr;
+    RGP_HIP(hipMalloc(&buf, (size_t)n * 2 * sizeof(int)));
+    wgrad_row_tables_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(g, (int)n, buf, buf + n);
+    RGP_HIP(hipGetLastError());
+    RGP_HIP(hipStreamSynchronize(s));                          // visible to every stream that uses the cached pointers
+    it = cache.emplace(key, std::make_pair(buf, buf + n)).first;
+  }
+  *x_tab = it->second.first;
+  *y_tab = it->second.second;
+  return RGP_OK;
+}
 
 int set_err(int code, const char* fmt, ...) {
   va_list ap;

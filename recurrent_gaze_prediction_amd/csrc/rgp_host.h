@@ -53,6 +53,17 @@ constexpr int dev_knob(const char*, int dflt) { return dflt; }
 int ensure_dyn_smem(const void* kernel, int bytes);
 int device_cu_count(int* n_cu);
 
+// Row tables of the filter-gradient kernel (wgrad.hip.h): byte offset of row m = (z*H + y)*W + x of a D x H x W grid
+// from its image in X (z*x_sz + y*x_sy + x*x_sx elements) and in dY (y_org + z*y_sz + y*y_sy + x*y_sx), entries
+// [0, D*H*W + 32), entry e >= D*H*W continuing into the following image(s).  Built on the device the first time a
+// geometry is seen on the current device (one hipMalloc + one small kernel on `s`, then cached for the life of the
+// process); the first use of a geometry must therefore not happen inside a stream capture.
+struct WgradGeom {
+  int D, H, W, x_sz, x_sy, x_sx, y_sz, y_sy, y_sx, y_org, esz;
+  long long x_img_stride, y_img_stride;
+};
+int wgrad_row_tables(const WgradGeom& g, hipStream_t s, const int** x_tab, const int** y_tab);
+
 struct Arena {
   size_t off = 0;
   size_t take(size_t bytes) {

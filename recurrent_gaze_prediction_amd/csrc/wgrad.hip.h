@@ -30,12 +30,16 @@ struct WgradParams {
                            // its first 128*sizeof(T) bytes must be zero (they are: halo)
   float* dW;               // [nk*BKE][ldw] fp32, accumulated with atomics
   // Row m of an image is the output position (z, y, x), m = (z*H + y)*W + x.  Its window origin in X is
-  // z*x_sz + y*x_sy + x*x_sx elements, its position in dY is y_org + z*y_sz + y*y_sy + x*y_sx.  The offsets
-  // are computed, not looked up: a per-lane table load inside the loop would sit in the same in-order
-  // vmcnt queue as the LDS-DMA and force the ring to drain.
+  // z*x_sz + y*x_sy + x*x_sx elements, its position in dY is y_org + z*y_sz + y*y_sy + x*y_sx: wgrad_row_tables()
+  // (rgp_host.h) tabulates both as BYTE offsets from the image, x_tab / y_tab [Mw + 32], entry e >= Mw continuing into
+  // the following image(s).  A 32-row step starts at a (scalar) image and row ml0 and row r of it is entry ml0 + r, so
+  // the loop's per-lane work is one table load per owned row, issued one step ahead and IN FRONT of that step's LDS-DMA
+  // in the in-order vmcnt queue (the counted wait that lets one step of DMA stay in flight then also covers it), and
+  // one add per DMA.  (The first version recomputed z*sz + y*sy + x*sx per row and step with float reciprocals: 8 VALU
+  // instructions per MFMA, 16 of every 110 the quarter-rate v_mul_lo_u32 -- the matrix pipe was 36 % busy.)
+  const int *x_tab, *y_tab;
   int D, H, W;
   int x_sz, x_sy, x_sx, y_sz, y_sy, y_sx, y_org;
-  float inv_W, inv_H, inv_D;
   const int* koff;         // [nk*G] element offset of each K (sub-)chunk
   long long x_img_stride, y_img_stride;
   long long M;             // rows = images * Mw
@@ -65,14 +69,10 @@ template <typename T> __device__ __forceinline__ int wg_swz_y(int r) {
   return sizeof(T) == 2 ? 2 * ((r & 3) | (((r >> 3) & 1) << 2)) : 0;
 }
 
-// STAG (bf16, WNT = 8, one block per CU): the two wave groups 0-3 / 4-7 (partners on a SIMD) run half a step apart,
-//   LOAD(s): fragment reads of step s, DMA of step s+2, counted vmcnt, barrier     COMPUTE(s): 32 MFMAs, barrier
-// so one wave of a SIMD is in its MFMAs while the other reads (igemm_stagger.hip.h).  Without it the 256-wide tile
-// -- a third fewer LDS-DMA bytes per FLOP than two co-resident 128-wide blocks -- loses what it saves to exposed
-// LDS latency (its two waves per SIMD read, wait and compute in lockstep).
-template <typename T, int G, int WNT, bool STAG = false>
+template <int V> struct WgInt { static constexpr int value = V; };
+
+template <typename T, int G, int WNT>
 __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad_kernel(const WgradParams p) {
-  static_assert(!STAG || (WNT == 8 && sizeof(T) == 2), "staggered schedule: bf16, 256-wide tile");
   constexpr int ESZ = sizeof(T);
   constexpr int BKE = Elem<T>::BKE;               // filter rows per K-chunk (64 bf16, 32 fp32)
   constexpr int CI = BKE / 16;                    // 16-row tiles per chunk
@@ -103,73 +103,92 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
   // ---- DMA source bookkeeping: each thread owns one X row (2 chunks of it) and NYL dY rows ----
   const int xr = 8 * (wave & 3) + (lane >> 3);              // tile row of this thread's X loads
   const int xc = (lane & 7) ^ wg_swz_x<T>(xr);              // logical 16-B chunk it fetches
-  const char* xsrc_k[2];                                    // chunk-dependent part (koff), fixed per block
+  unsigned xk[2];                                           // chunk-dependent byte offset (koff), fixed per block
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     int kc = kt * 4 + (wave >> 2) + 2 * u;
     if (kc >= p.nk) kc = p.nk - 1;                          // duplicate work, never stored
     const int elems_per_sub = BKE / G, ce = xc * (16 / ESZ);
     const int sub = ce / elems_per_sub, off = ce - sub * elems_per_sub;
-    xsrc_k[u] = (const char*)p.X + ((long long)p.koff[kc * G + sub] + off) * ESZ;
+    xk[u] = (unsigned)((p.koff[kc * G + sub] + off) * ESZ);
   }
   // dY: lane-load q = tid + 512 u covers tile row q / CPR, physical chunk q % CPR (the LDS image is lane-linear)
-  int yr[NYL], yc[NYL];
+  int yr[NYL];
+  unsigned yk[NYL], yz[NYL];
 #pragma unroll
   for (int u = 0; u < NYL; ++u) {
     const int q = tid + 512 * u;
     yr[u] = q / CPR;
-    yc[u] = (q % CPR) ^ wg_swz_y<T>(yr[u]);
+    const int yc = (q % CPR) ^ wg_swz_y<T>(yr[u]);
+    yk[u] = (unsigned)(n0 * ESZ + yc * 16);
+    yz[u] = (unsigned)((yc & 7) * 16);                      // zeros (the image's leading halo) for rows beyond the range
   }
-  // running (image, z, y, x) of each owned row; a step advances every row by 32
-  struct RowPos { int img, z, y, x; };
-  auto locate = [&](long long m) {
-    RowPos r;
-    r.img = (int)(m / p.Mw);
-    int ml = (int)(m - (long long)r.img * p.Mw);
-    r.x = ml % p.W; ml /= p.W;
-    r.y = ml % p.H;
-    r.z = ml / p.H;
-    return r;
-  };
-  auto advance = [&](RowPos& r) {
-    r.x += 32;
-    int t = (int)(((float)r.x + 0.5f) * p.inv_W); r.x -= t * p.W; r.y += t;
-    t = (int)(((float)r.y + 0.5f) * p.inv_H); r.y -= t * p.H; r.z += t;
-    t = (int)(((float)r.z + 0.5f) * p.inv_D); r.z -= t * p.D; r.img += t;
-  };
-  RowPos xpos = locate(m_begin + xr), ypos[NYL];
+  // scalar position of the next step to issue: image img0, row ml0 of it; a step advances it by 32 rows
+  const int adv_img = 32 / p.Mw, adv_ml = 32 - adv_img * p.Mw;
+  long long img0 = m_begin / p.Mw;
+  int ml0 = (int)(m_begin - img0 * p.Mw);
+  int rows_left = (int)(m_end - m_begin);                   // rows of this block's range not yet issued
+  // table entries of the step to issue next (landed: see the vmcnt waits)
+  unsigned tx, ty[NYL];
+  auto load_tabs = [&]() {
+    const int* xt = p.x_tab + ml0;
+    const int* yt = p.y_tab + ml0;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(tx) : "v"(xr * 4), "s"(xt) : "memory");
 #pragma unroll
-  for (int u = 0; u < NYL; ++u) ypos[u] = locate(m_begin + yr[u]);
-  int n_issued = 0;
+    for (int u = 0; u < NYL; ++u) asm volatile("global_load_dword %0, %1, %2" : "=v"(ty[u]) : "v"(yr[u] * 4), "s"(yt) : "memory");
+  };
+  auto tabs_landed = [&]() {                                 // behind a wait that covers them: re-define the registers
+    asm volatile("" : "+v"(tx));
+#pragma unroll
+    for (int u = 0; u < NYL; ++u) asm volatile("" : "+v"(ty[u]));
+  };
 
+  // issue the LDS-DMA of the next step (its table entries are in tx / ty) and, in front of it, the table loads of the
+  // step after
   auto issue = [&](int buf) {
     char* xb = smem + buf * S::STAGE;
     char* yb = xb + S::XB;
-    const long long m_step = m_begin + (long long)n_issued * 32;
-    {
-      const bool ok = m_step + xr < m_end;
-      const long long base = ((long long)xpos.img * p.x_img_stride + xpos.z * p.x_sz + xpos.y * p.x_sy + xpos.x * p.x_sx) * ESZ;
+    const char* ximg = (const char*)p.X + img0 * p.x_img_stride * ESZ;
+    const char* yimg = (const char*)p.dY + img0 * p.y_img_stride * ESZ;
+    unsigned xo[2], yo[NYL];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const char* src = ok ? xsrc_k[u] + base : (const char*)p.X;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+    for (int u = 0; u < 2; ++u) xo[u] = tx + xk[u];
+#pragma unroll
+    for (int u = 0; u < NYL; ++u) yo[u] = ty[u] + yk[u];
+    const int rl = rows_left;
+    rows_left -= 32;
+    img0 += adv_img;
+    ml0 += adv_ml;
+    if (ml0 >= p.Mw) { ml0 -= p.Mw; ++img0; }
+    load_tabs();
+    auto dma = [&](const char* const (&xs)[2], const char* const (&ys)[NYL]) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xs[u],
                                          (__attribute__((address_space(3))) void*)(xb + ((wave >> 2) + 2 * u) * 4096 + (wave & 3) * 1024),
                                          16, 0, 0);
-      }
-      advance(xpos);
-    }
 #pragma unroll
-    for (int u = 0; u < NYL; ++u) {
-      const bool ok = m_step + yr[u] < m_end;
-      const RowPos& r = ypos[u];
-      const char* src = (const char*)p.dY;
-      if (ok) src += ((long long)r.img * p.y_img_stride + p.y_org + r.z * p.y_sz + r.y * p.y_sy + r.x * p.y_sx + n0) * ESZ + yc[u] * 16;
-      else src += (yc[u] & 7) * 16;                                        // zeros (halo)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(yb + wave * 1024 + u * 8192), 16, 0, 0);
-      advance(ypos[u]);
+      for (int u = 0; u < NYL; ++u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ys[u],
+                                         (__attribute__((address_space(3))) void*)(yb + wave * 1024 + u * 8192), 16, 0, 0);
+    };
+    const char *xs[2], *ys[NYL];
+    if (rl >= 32) {                                          // scalar image base + 32-bit lane offset
+#pragma unroll
+      for (int u = 0; u < 2; ++u) xs[u] = ximg + xo[u];
+#pragma unroll
+      for (int u = 0; u < NYL; ++u) ys[u] = yimg + yo[u];
+      dma(xs, ys);
+    } else {
+      // the range's last (partial) step and the ones beyond it (issued for a uniform vmcnt arithmetic): rows past the
+      // end read the zeros at the start of dY against finite values of X
+#pragma unroll
+      for (int u = 0; u < 2; ++u) xs[u] = xr < rl ? ximg + xo[u] : (const char*)p.X;
+#pragma unroll
+      for (int u = 0; u < NYL; ++u) ys[u] = yr[u] < rl ? yimg + yo[u] : (const char*)p.dY + yz[u];
+      dma(xs, ys);
+      asm volatile("; partial step" ::: "memory");           // keeps the two arms apart: merged, the full steps lose the scalar base
     }
-    ++n_issued;
   };
 
   f32x4 acc[CI][WNT];
@@ -184,56 +203,52 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
   const int my_rows = (kt * 4 + wk < p.nk) ? p.k_valid - (kt * 4 + wk) * BKE : 0;
   const int ci_n = my_rows <= 0 ? 0 : (my_rows >= BKE ? CI : (my_rows + 15) >> 4);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  auto compute = [&](int buf) {
-    const char* xb = smem + buf * S::STAGE + wk * 4096;
-    const char* yb = smem + buf * S::STAGE + S::XB;
+  // per-thread LDS read addresses of ring stage 0 (stage 1 = + STAGE as an immediate, stage 2 has its own registers:
+  // 2 * STAGE does not fit the 16-bit offset field of the 256-wide tile)
+  const int rq = fcol >> 2, rp = fcol & 3;
+  const int rrow = 8 * g + rq;                                 // rows rrow and rrow+4 share the swizzle
+  unsigned xa0[4], ya0[WNT], xa2[4], ya2[WNT];
+  {
+    const int sx = (wg_swz_x<T>(rrow) >> 1), sy = (wg_swz_y<T>(rrow) >> 1);
+    const unsigned xa = lds_base + wk * 4096 + rrow * 128 + rp * 8;
+    const unsigned ya = lds_base + S::XB + rrow * YROW + rp * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xa0[k] = xa + ((k ^ sx) * 32); xa2[k] = xa0[k] + 2 * S::STAGE; }
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) { ya0[j] = ya + (((wn * WNT + j) ^ sy) * 32); ya2[j] = ya0[j] + 2 * S::STAGE; }
+  }
+  auto compute = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
     if constexpr (ESZ == 2) {
-      const int q = fcol >> 2, pp = fcol & 3;
-      const int row = 8 * g + q;                                 // rows row and row+4 share the swizzle
-      const int sx = (wg_swz_x<T>(row) >> 1), sy = (wg_swz_y<T>(row) >> 1);
       // The transposing reads are written as inline asm: issued through the builtin, the compiler orders
       // every LDS read after ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which drains the two tiles in
       // flight and serialises the ring.  The asm carries its own lgkmcnt wait; A's registers are consumed
       // only by MFMAs that also need B's, so one wait at the end of the last block covers them all.
       static_assert(CI == 4, "bf16 chunk = 4 x 16 filter rows");
-      const unsigned xa = lds_base + (unsigned)(xb - smem) + row * 128 + pp * 8;
-      const unsigned ya = lds_base + (unsigned)(yb - smem) + row * YROW + pp * 8;
+      constexpr int OB = buf == 1 ? S::STAGE : 0;
+      const unsigned (&xa)[4] = buf == 2 ? xa2 : xa0;
+      const unsigned (&ya)[WNT] = buf == 2 ? ya2 : ya0;
       i32x2 al[4], ah[4], bl[WNT], bh[WNT];
       asm volatile(
-          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
-          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:512\n\t"
-          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:512\n\t"
-          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:512"
+          "ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+          "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+          "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+          "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
           : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&v"(al[3]), "=&v"(ah[3])
-          : "v"(xa + ((0 ^ sx) * 32)), "v"(xa + ((1 ^ sx) * 32)), "v"(xa + ((2 ^ sx) * 32)), "v"(xa + ((3 ^ sx) * 32))
+          : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "n"(OB), "n"(OB + 512)
           : "memory");
-      // rows row+4 of the dY tile are 4*YROW bytes further: 1024 (BN 128) or 2048 (BN 256)
+      // rows rrow+4 of the dY tile are 4*YROW bytes further: 1024 (BN 128) or 2048 (BN 256)
 #pragma unroll
-      for (int jb = 0; jb < WNT; jb += 4) {
-        if constexpr (WNT == 4) {
-          asm volatile(
-              "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
-              "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
-              "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
-              "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:1024"
-              : "=&v"(bl[jb]), "=&v"(bh[jb]), "=&v"(bl[jb + 1]), "=&v"(bh[jb + 1]), "=&v"(bl[jb + 2]), "=&v"(bh[jb + 2]), "=&v"(bl[jb + 3]),
-                "=&v"(bh[jb + 3])
-              : "v"(ya + (((wn * WNT + jb + 0) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 1) ^ sy) * 32)),
-                "v"(ya + (((wn * WNT + jb + 2) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 3) ^ sy) * 32))
-              : "memory");
-        } else {
-          asm volatile(
-              "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
-              "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
-              "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
-              "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:2048"
-              : "=&v"(bl[jb]), "=&v"(bh[jb]), "=&v"(bl[jb + 1]), "=&v"(bh[jb + 1]), "=&v"(bl[jb + 2]), "=&v"(bh[jb + 2]), "=&v"(bl[jb + 3]),
-                "=&v"(bh[jb + 3])
-              : "v"(ya + (((wn * WNT + jb + 0) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 1) ^ sy) * 32)),
-                "v"(ya + (((wn * WNT + jb + 2) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 3) ^ sy) * 32))
-              : "memory");
-        }
-      }
+      for (int jb = 0; jb < WNT; jb += 4)
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+            "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+            "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+            "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+            : "=&v"(bl[jb]), "=&v"(bh[jb]), "=&v"(bl[jb + 1]), "=&v"(bh[jb + 1]), "=&v"(bl[jb + 2]), "=&v"(bh[jb + 2]), "=&v"(bl[jb + 3]),
+              "=&v"(bh[jb + 3])
+            : "v"(ya[jb]), "v"(ya[jb + 1]), "v"(ya[jb + 2]), "v"(ya[jb + 3]), "n"(OB), "n"(OB + 4 * YROW)
+            : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // the fragment registers are valid only behind the wait: re-define them there
 #pragma unroll
@@ -258,6 +273,8 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
           for (int j = 0; j < WNT; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
         }
     } else {
+      const char* xb = smem + buf * S::STAGE + wk * 4096;
+      const char* yb = smem + buf * S::STAGE + S::XB;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int row = 4 * s + g;
@@ -276,106 +293,31 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
     }
   };
 
-  // STAG: the same reads / MFMAs as compute(), split around the group barrier (fragments live in registers across it)
-  i32x2 s_al[4], s_ah[4], s_bl[WNT], s_bh[WNT];
-  auto stag_reads = [&](int buf) {
-    if constexpr (STAG) {
-      const char* xb = smem + buf * S::STAGE + wk * 4096;
-      const char* yb = smem + buf * S::STAGE + S::XB;
-      const int q = fcol >> 2, pp = fcol & 3;
-      const int row = 8 * g + q;
-      const int sx = (wg_swz_x<T>(row) >> 1), sy = (wg_swz_y<T>(row) >> 1);
-      const unsigned xa = lds_base + (unsigned)(xb - smem) + row * 128 + pp * 8;
-      const unsigned ya = lds_base + (unsigned)(yb - smem) + row * YROW + pp * 8;
-      asm volatile(
-          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
-          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:512\n\t"
-          "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:512\n\t"
-          "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:512"
-          : "=&v"(s_al[0]), "=&v"(s_ah[0]), "=&v"(s_al[1]), "=&v"(s_ah[1]), "=&v"(s_al[2]), "=&v"(s_ah[2]), "=&v"(s_al[3]), "=&v"(s_ah[3])
-          : "v"(xa + ((0 ^ sx) * 32)), "v"(xa + ((1 ^ sx) * 32)), "v"(xa + ((2 ^ sx) * 32)), "v"(xa + ((3 ^ sx) * 32))
-          : "memory");
-#pragma unroll
-      for (int jb = 0; jb < WNT; jb += 4)
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:2048\n\t"
-            "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:2048"
-            : "=&v"(s_bl[jb]), "=&v"(s_bh[jb]), "=&v"(s_bl[jb + 1]), "=&v"(s_bh[jb + 1]), "=&v"(s_bl[jb + 2]), "=&v"(s_bh[jb + 2]),
-              "=&v"(s_bl[jb + 3]), "=&v"(s_bh[jb + 3])
-            : "v"(ya + (((wn * WNT + jb + 0) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 1) ^ sy) * 32)),
-              "v"(ya + (((wn * WNT + jb + 2) ^ sy) * 32)), "v"(ya + (((wn * WNT + jb + 3) ^ sy) * 32))
-            : "memory");
-    }
-  };
-  auto stag_mma = [&]() {
-    if constexpr (STAG) {
-      // the fragment registers are valid only behind the lgkmcnt(0) of the LOAD phase: re-define them here
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(s_al[i]), "+v"(s_ah[i]));
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) asm volatile("" : "+v"(s_bl[j]), "+v"(s_bh[j]));
-      f32x4 a[CI], b[WNT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const i32x4 va = {s_al[i][0], s_al[i][1], s_ah[i][0], s_ah[i][1]};
-        a[i] = __builtin_bit_cast(f32x4, va);
-      }
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        const i32x4 vb = {s_bl[j][0], s_bl[j][1], s_bh[j][0], s_bh[j][1]};
-        b[j] = __builtin_bit_cast(f32x4, vb);
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < CI; ++i)
-        if (i < ci_n) {
-#pragma unroll
-          for (int j = 0; j < WNT; ++j) Mma<T>::step(acc[i][j], a[i], b[j]);
-        }
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
   // ---- 3-stage ring: steps s+1 and s+2 are in flight while step s is consumed.  Steps beyond the
   // block's range are issued too (they fetch zeros), so the vmcnt arithmetic is uniform. ----
-  issue(0);
-  issue(1);
-  if constexpr (STAG) {
-    // Hazards as in igemm_stagger.hip.h (h = half-step; group A loads step s at h = 2s, computes at 2s+1; B one later):
-    //  RAW  step s is read from h = 2s on; its DMA was issued in LOAD(s-2) and every wave passed vmcnt(PER_STEP) for it
-    //       in LOAD(s-1) before that phase's barrier (A: end of 2s-2, B: end of 2s-1).
-    //  WAR  the DMA of step s+2 overwrites the stage of step s-1, last read in LOAD(s-1) (A: 2s-2, B: 2s-1, each followed
-    //       by lgkmcnt(0) + barrier); it is issued at h >= 2s.
-    const bool group_b = wave >= 4;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");   // step 0 landed
-    __builtin_amdgcn_s_barrier();
-    if (group_b) __builtin_amdgcn_s_barrier();
-#pragma clang loop unroll(disable)
-    for (int s = 0; s < nsteps; ++s) {
-      stag_reads(s % 3);
-      __builtin_amdgcn_sched_barrier(0);
-      issue((s + 2) % 3);                                            // (beyond the range: zeros, uniform vmcnt arithmetic)
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_STEP) : "memory");   // step s+1 landed, fragments in registers
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      stag_mma();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!group_b) __builtin_amdgcn_s_barrier();
-  } else {
-#pragma clang loop unroll(disable)
-  for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
+  load_tabs();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tabs_landed();
+  issue(0);                                                         // queue: T(1) DMA(0)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");   // T(1) landed
+  tabs_landed();
+  issue(1);                                                         // queue: DMA(0) T(2) DMA(1)
+  auto step = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");   // all but DMA(s+1): DMA(s) and T(s+2) landed
+    tabs_landed();
     if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();           // step s landed for every wave; stage (s+2)%3 is free
-    if (!(p.ablate & 2)) issue((s + 2) % 3);
-    if (!(p.ablate & 1) && ci_n > 0) compute(s % 3);
-  }
+    if (!(p.ablate & 2)) issue((buf + 2) % 3);
+    if (!(p.ablate & 1) && ci_n > 0) compute(BUF);
+  };
+  // written out over the ring's three stages: every LDS address of the loop is a register + an immediate
+  for (int s = 0; s < nsteps;) {
+    step(WgInt<0>{});
+    if (++s >= nsteps) break;
+    step(WgInt<1>{});
+    if (++s >= nsteps) break;
+    step(WgInt<2>{});
+    ++s;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

@@ -8,9 +8,9 @@
 
 namespace rgp {
 
-template <typename T, int G, int WNT, bool STAG = false>
+template <typename T, int G, int WNT>
 int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
-  auto kern = wgrad_kernel<T, G, WNT, STAG>;
+  auto kern = wgrad_kernel<T, G, WNT>;
   constexpr int smem = WgradSmem<T, WNT>::BYTES;
   constexpr int BN = 32 * WNT;
   RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
@@ -22,6 +22,10 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
   long long splits = std::max<long long>(8, target / (n_kt * n_nt));
   splits = std::min(splits, total_steps);
   WgradParams q = p;
+  {
+    const WgradGeom g = {p.D, p.H, p.W, p.x_sz, p.x_sy, p.x_sx, p.y_sz, p.y_sy, p.y_sx, p.y_org, (int)sizeof(T), p.x_img_stride, p.y_img_stride};
+    RGP_TRY(wgrad_row_tables(g, s, &q.x_tab, &q.y_tab));
+  }
   q.ablate = dev_knob("RGP_WG_ABLATE", 0);
   q.steps_per_split = (int)((total_steps + splits - 1) / splits);
   splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
@@ -33,17 +37,13 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
 // The 256-wide tile (one block per CU, a third fewer LDS-DMA bytes per FLOP) pays only for few tiles with a long
 // reduction -- conv3a / conv3b: -3 % -- and loses 5...15 % where the 128-wide kernel already has hundreds of
 // tiles (conv4*, conv5*: two co-resident blocks hide each other's barriers).  RGP_WG_WIDE=0 / 2 forces never / always.
+// (A variant with the two wave groups of the 256-wide tile running half a step apart, as in igemm_stagger.hip.h, measured
+// no gain on the fine-tune step and was removed.)
 template <typename T, int G>
 int launch_wgrad(const WgradParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     const int wide = dev_knob("RGP_WG_WIDE", 1);
     const int narrow_tiles = ((p.nk + 3) / 4) * ((p.N + 127) / 128);
-#ifdef RGP_DEV_KNOBS
-    // RGP_WG_WIDE=3: staggered 256-wide tile whenever N % 256 == 0.  Measured on the fine-tune step (B16 x T16, one
-    // box, interleaved): 60.3 / 60.3 ms default vs 60.6 / 60.3 ms -- no gain: the loop is bound by its one transposing
-    // LDS read per MFMA (reads + MFMA alone run at 0.9 PFLOP/s), not by the overlap of its phases.  Dev build only.
-    if (G == 1 && wide == 3 && p.N % 256 == 0) return launch_wgrad_t<T, G, 8, G == 1>(p, s);
-#endif
     if (wide && p.N % 256 == 0 && (wide == 2 || narrow_tiles <= 64)) return launch_wgrad_t<T, G, 8>(p, s);
   }
   return launch_wgrad_t<T, G, 4>(p, s);
@@ -52,7 +52,6 @@ int launch_wgrad(const WgradParams& p, hipStream_t s) {
 // geometry helpers: rows of one image are the positions (z, y, x) of a D x H x W grid
 inline void wgrad_grid(WgradParams& p, int D, int H, int W) {
   p.D = D; p.H = H; p.W = W;
-  p.inv_D = 1.0f / D; p.inv_H = 1.0f / H; p.inv_W = 1.0f / W;
   p.Mw = D * H * W;
 }
 
