@@ -1,0 +1,283 @@
+// C3D conv2a (3x3x3, 64->128, pad 1) + bias + ReLU + pool2 (2x2x2 max) for gfx950, bf16, inference.
+// Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:67-107.
+//
+// Why a kernel of its own: conv2a is the largest layer of the stack (22.7 of 78.8 TFLOP per 1024 windows) and the one
+// the general implicit-GEMM tile serves worst.  With N = 128 only the A tile can grow, and the A operand -- one
+// 64-byte row per output position and 32-deep K step, gathered from L2 by LDS-DMA -- is re-fetched for each of the 27
+// taps: the 512 x 128 tile of igemm_wide.hip.h moves 40 KB L2 -> LDS per 4.2 MFLOP, 39 B per cycle and CU at full
+// MFMA rate against the 28...35 B per cycle an MI355X CU ingests (MI355X_MICROARCH.md: 66-73 GB/s), and its matrix
+// pipe is 62 % busy.  Here the input PATCH of a tile is brought into LDS once per channel half and the fragments of
+// all 27 taps are read from it at shifted addresses (what conv1a.hip.h does for the first layer):
+//
+//  * tile = 2 pooled rows x 28 pooled columns of one pooled plane of one window = 56 pooling windows = 448 conv
+//    outputs x 128 channels; its input is 4 planes x 6 rows x 58 pixels of act1 [n][18][58][58][64].  A plane slab is
+//    348 consecutive pixels in memory (full rows incl. the x halo); 24 LDS-DMA instructions bring 64 B (one channel
+//    half) of each of 384 pixels into a 24 KB plane buffer.
+//  * K order: channel half cc (2) x tap (27, kz-major) x 32 channels.  A K step reads, per wave, 7 A fragments from
+//    the patch at (row base + plane base) + immediate (ky*58 + kx)*64, and 4 B fragments from a ring of 8 KB filter
+//    slabs (the packed filter of the general kernel, [128][tap*64 + c]).  L2 -> LDS per step: 8 KB of filter + 96 KB
+//    of patch per 27 steps = 11.6 KB (was 40).
+//  * plane buffers: the rows with dz = 0 read plane kz, those with dz = 1 plane kz + 1, so plane 0 is free after the
+//    kz = 0 taps and plane 1 after kz = 1: the next sweep's planes 0 / 1 are fetched at the start of this sweep's
+//    kz = 1 / kz = 2 tap groups and its planes 2, 3 at the start of its own kz = 0 group -- four buffers, no stall.
+//  * banks: an A-fragment read (ds_read_b128; 16 rows = 2 adjacent pooling windows x (dz,dy,dx), 4 K chunks) touches
+//    runs of 4 consecutive pixels (256 B) on rows whose pitch is 58*64 = 128 (mod 256), and the plane buffers start
+//    at 32 (k & 1) (mod 256): every 16-lane group of the read covers the 64 banks exactly once.  No swizzle.
+//  * rows are ordered (pooling window, dz, dy, dx): a lane's 4 accumulator registers + the lane 16 further hold one
+//    window, pool2 is a max3 tree and one ds_swizzle; the pooled 56 x 128 tile goes through LDS for 16-byte stores.
+//  * schedule: the two-group staggered loop of igemm_wide.hip.h (waves 0-3 / 4-7, partners on a SIMD, half a step
+//    apart: LOAD = fragment reads + DMA issue + counted wait, COMPUTE = 28 MFMAs), waves 4 (M) x 2 (N), 112 x 64 each.
+#pragma once
+#include <type_traits>
+
+#include "igemm.hip.h"
+
+namespace rgp {
+
+struct Conv2aParams {
+  const bf16_t* in;     // act1 [n][18][58][58][64]
+  const bf16_t* wp;     // packed filter [128][1728], K index = tap*64 + c
+  const float* bias;    // [128]
+  bf16_t* out;          // act2 [n][10][30][30][128]
+  int n_windows;
+};
+
+constexpr int C2_PLANE_PIX = 384;                       // pixels fetched per plane slab (348 used)
+constexpr int C2_PLANE_BYTES = C2_PLANE_PIX * 64;       // 24 576
+constexpr int C2_PLANE_STRIDE = C2_PLANE_BYTES + 256;
+constexpr int C2_BRING_OFF = 99328;                     // 4 plane buffers end at 3*24832 + 32 + 24576 = 99 104
+constexpr int C2_BSLOT = 128 * 64;                      // 8 KB: 128 filter rows x 32 K elements
+constexpr int C2_NSLOT = 4, C2_AHEAD = 3;
+constexpr int C2_SMEM = C2_BRING_OFF + C2_NSLOT * C2_BSLOT;     // 132 096
+constexpr int C2_STG_LD = 128 + 4;                      // staged pooled tile: 56 x 132 floats over the filter ring
+static_assert(56 * C2_STG_LD * 4 <= C2_NSLOT * C2_BSLOT, "pooled tile fits the ring");
+constexpr int C2_TILES_PER_WINDOW = 8 * 14;
+constexpr int C2_IN_PLANE = 58 * 58 * 64, C2_IN_IMG = 18 * C2_IN_PLANE;      // elements
+constexpr int C2_OUT_ROW = 30 * 128, C2_OUT_PLANE = 30 * C2_OUT_ROW, C2_OUT_IMG = 10 * C2_OUT_PLANE;
+
+template <int OFF>
+static __device__ __forceinline__ f32x4 c2_lds_read128(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+static __device__ __forceinline__ unsigned c2_plane_base(int k) { return (unsigned)(k * C2_PLANE_STRIDE + 32 * (k & 1)); }
+
+static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Conv2aParams p) {
+  extern __shared__ __attribute__((aligned(16))) char c2_smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)c2_smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool group_b = wave >= 4;
+  const int frow = lane & 15, fk = lane >> 4;
+
+  // persistent tile walk: XCD x (workgroup id & 7) owns a contiguous range of tiles (neighbouring tiles share halo rows
+  // and planes: one L2 serves them)
+  const int nt = p.n_windows * C2_TILES_PER_WINDOW;
+  auto tile_of = [&](int t) {
+    const int q = nt >> 3, r = nt & 7, x = t & 7, y = t >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+  };
+  int t_seq = blockIdx.x;
+  if (t_seq >= nt) return;
+
+  // source of plane k of (tile, channel half): element offset into `in`
+  auto plane_src = [&](int tile, int cc, int k) -> const char* {
+    const int n = tile / C2_TILES_PER_WINDOW, r = tile - n * C2_TILES_PER_WINDOW;
+    const int zp = r / 14, yp = r - zp * 14;
+    return (const char*)(p.in + (long long)n * C2_IN_IMG + (long long)(2 * zp + k) * C2_IN_PLANE + (4 * yp) * (58 * 64) + cc * 32);
+  };
+  // this wave's 3 of the 24 DMA instructions of a plane: 16 pixels x 64 B each
+  const int dpix = lane >> 2, dchk = lane & 3;
+  auto dma_plane = [&](const char* src, int k) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = wave * 3 + u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 16 + dpix) * 128 + dchk * 16),
+                                       (__attribute__((address_space(3))) void*)(c2_smem + c2_plane_base(k) + j * 1024), 16, 0, 0);
+    }
+  };
+  // filter slab of K step (cc, tap): this wave's 1 of 8 instructions (16 filter rows x 64 B), chunk-swizzled like
+  // igemm_wide.hip.h (physical chunk c of row r holds logical chunk c ^ ((-(r >> 2)) & 3))
+  const int brow = lane >> 2;
+  const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
+  const char* b_src = (const char*)(p.wp + (long long)(wave * 16 + brow) * 1728) + bchk * 16;
+  auto dma_b = [&](int slot, int cc, int tap) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (tap * 2 + cc) * 64),
+                                     (__attribute__((address_space(3))) void*)(c2_smem + C2_BRING_OFF + slot * C2_BSLOT + wave * 1024), 16, 0, 0);
+  };
+
+  // fragment addressing.  m-tile i of this wave = pooling windows 2 (7 wm + i), +1; row frow of it: window frow >> 3,
+  // dz = (frow >> 2) & 1, dy = (frow >> 1) & 1, dx = frow & 1; K chunk fk.
+  const int r_ws = frow >> 3, r_dz = (frow >> 2) & 1, r_dy = (frow >> 1) & 1, r_dx = frow & 1;
+  unsigned rowaddr[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int w0 = 2 * (7 * wm + i);
+    const int ypl = w0 / 28, xp = w0 - ypl * 28 + r_ws;
+    rowaddr[i] = lds0 + ((2 * ypl + r_dy) * 58 + 2 * xp + r_dx) * 64 + fk * 16;
+  }
+  const unsigned b_addr = lds0 + C2_BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
+
+  while (true) {
+    const int tile = tile_of(t_seq);
+    const int t_next = t_seq + gridDim.x;
+    const bool has_next = t_next < nt;
+    const int tile_next = has_next ? tile_of(t_next) : tile;
+
+    f32x4 acc[7][4];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: planes 0, 1 of the first sweep (the first tile only: later tiles find them prefetched), filter slabs
+    // of steps 0 .. 2 ----
+    if (t_seq == (int)blockIdx.x) {
+      dma_plane(plane_src(tile, 0, 0), 0);
+      dma_plane(plane_src(tile, 0, 1), 1);
+    }
+    dma_b(0, 0, 0);
+    dma_b(1, 0, 1);
+    dma_b(2, 0, 2);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // planes 0, 1 and slab 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (group_b) __builtin_amdgcn_s_barrier();               // run one half-step behind group A
+
+    int slot = 0;
+    // one group of 9 taps (ky, kx) of plane offset kz, K steps s0 .. s0 + 8 of the tile; NPL plane fetches (3
+    // instructions per wave each) are issued in its first LOAD phase
+    auto tap_group = [&](auto NPL_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb) {
+      constexpr int NPL = decltype(NPL_)::value;
+      unsigned ra[7];
+      const unsigned pb = r_dz ? c2_plane_base(kz + 1) : c2_plane_base(kz);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) ra[i] = rowaddr[i] + pb;
+      const int s0 = cc * 27 + kz * 9;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        // ---------------- LOAD ----------------
+        const int s = s0 + t9;
+        f32x4 af[7], bf[4];
+        const unsigned bb = b_addr + slot * C2_BSLOT;
+        auto reads = [&](auto T9) {
+          constexpr int t = decltype(T9)::value;
+          constexpr int imm = ((t / 3) * 58 + (t % 3)) * 64;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) af[i] = c2_lds_read128<imm>(ra[i]);
+        };
+        switch (t9) {
+          case 0: reads(std::integral_constant<int, 0>{}); break;
+          case 1: reads(std::integral_constant<int, 1>{}); break;
+          case 2: reads(std::integral_constant<int, 2>{}); break;
+          case 3: reads(std::integral_constant<int, 3>{}); break;
+          case 4: reads(std::integral_constant<int, 4>{}); break;
+          case 5: reads(std::integral_constant<int, 5>{}); break;
+          case 6: reads(std::integral_constant<int, 6>{}); break;
+          case 7: reads(std::integral_constant<int, 7>{}); break;
+          default: reads(std::integral_constant<int, 8>{}); break;
+        }
+        bf[0] = c2_lds_read128<0>(bb);
+        bf[1] = c2_lds_read128<1024>(bb);
+        bf[2] = c2_lds_read128<2048>(bb);
+        bf[3] = c2_lds_read128<3072>(bb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t9 == 0) {
+          if (NPL >= 1) dma_plane(pl_a, ka);
+          if (NPL >= 2) dma_plane(pl_b, kb);
+        }
+        {
+          // filter slab of step s + 3 (wraps into the next tile's steps 0 .. 2 at the end: re-fetched by its prologue,
+          // harmless and uniform)
+          int s3 = s + C2_AHEAD;
+          if (s3 >= 54) s3 -= 54;
+          const int cc3 = s3 >= 27 ? 1 : 0;
+          int slot3 = slot + C2_AHEAD;
+          if (slot3 >= C2_NSLOT) slot3 -= C2_NSLOT;
+          dma_b(slot3, cc3, s3 - cc3 * 27);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // slab s+1 landed: younger are slabs s+2, s+3 and, in the two steps after a plane fetch, its instructions
+        if (t9 < 2 && NPL == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (t9 < 2 && NPL == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bf[j]));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- COMPUTE ----------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 == C2_NSLOT ? 0 : slot + 1;
+      }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#pragma clang loop unroll(disable)
+    for (int cc = 0; cc < 2; ++cc) {
+      // the sweep after this one: the other channel half of this tile, or the first half of the next tile
+      const int ntile = cc == 0 ? tile : tile_next;
+      const int ncc = cc ^ 1;
+      tap_group(I2{}, cc, 0, plane_src(tile, cc, 2), 2, plane_src(tile, cc, 3), 3);
+      tap_group(I1{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0);
+      tap_group(I1{}, cc, 2, plane_src(ntile, ncc, 1), 1, nullptr, 0);
+    }
+    if (!group_b) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the wrapped slabs, and the next tile's planes 0, 1
+    __syncthreads();
+
+    // ---- epilogue: pool2 in registers, pooled tile through LDS (over the filter ring), bias + ReLU, 16-byte stores ----
+    float* stg = (float*)(c2_smem + C2_BRING_OFF);
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 c = acc[i][j];
+        const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+        const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
+        if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C2_STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
+      }
+    __syncthreads();
+    {
+      const int n = tile / C2_TILES_PER_WINDOW, r = tile - n * C2_TILES_PER_WINDOW;
+      const int zp = r / 14, yp = r - zp * 14;
+      bf16_t* obase = p.out + (long long)n * C2_OUT_IMG + (zp + 1) * C2_OUT_PLANE + (2 * yp + 1) * C2_OUT_ROW + 128;
+      const int cg = tid & 15;
+      float b8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b8[q] = p.bias[cg * 8 + q];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int w = (tid >> 4) + 32 * k;                    // pooling window 0 .. 55
+        if (w < 56) {
+          const float* src = stg + w * C2_STG_LD + cg * 8;
+          const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          u32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            o[q] = (unsigned)f2bf(fmaxf(v[2 * q] + b8[2 * q], 0.f)) | ((unsigned)f2bf(fmaxf(v[2 * q + 1] + b8[2 * q + 1], 0.f)) << 16);
+          const int ypl = w / 28, xp = w - ypl * 28;
+          *(u32x4*)(obase + ypl * C2_OUT_ROW + xp * 128 + cg * 8) = o;
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();                                           // staging read before the ring is refilled
+    t_seq = t_next;
+  }
+}
+
+}  // namespace rgp

@@ -1,7 +1,9 @@
 // librgp_hip.so: launch of the dedicated bf16 conv1a + bias + ReLU + pool1 kernel (conv1a.hip.h).
-// A translation unit of its own because it is compiled with -fno-honor-nans (see the header comment of conv1a.hip.h).
+// A translation unit of its own because it is compiled with -fno-honor-nans (see the header comment of conv1a.hip.h);
+// the dedicated conv2a kernel (conv2a_patch.hip.h) lives here too.
 #include "rgp_c3d_plan.h"
 #include "conv1a.hip.h"
+#include "conv2a_patch.hip.h"
 
 using namespace rgp;
 
@@ -36,4 +38,20 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video) {
   if (video) return launch(conv1a_pool_bf16_kernel<true, true>);
   if (p.argmax) return launch(conv1a_pool_bf16_kernel<false, true>);
   return launch(conv1a_pool_bf16_kernel<false, false>);
+}
+
+// bf16 inference conv2a + pool2 (conv2a_patch.hip.h); the training plan (arg-max codes) keeps the general kernel
+int run_conv2a_patch_bf16(rgp_c3d* c, int n, hipStream_t s) {
+  Conv2aParams p;
+  p.in = (const bf16_t*)(c->ws + c->act_off[1]);
+  p.wp = (const bf16_t*)(c->ws + c->L[1].w_off);
+  p.bias = c->bias[1];
+  p.out = (bf16_t*)(c->ws + c->act_off[2]);
+  p.n_windows = n;
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  RGP_TRY(ensure_dyn_smem((const void*)conv2a_patch_bf16_kernel, C2_SMEM));
+  conv2a_patch_bf16_kernel<<<n_cu, 512, C2_SMEM, s>>>(p);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
 }
