@@ -25,6 +25,8 @@
 //    at 32 (k & 1) (mod 256): every 16-lane group of the read covers the 64 banks exactly once.  No swizzle.
 //  * rows are ordered (pooling window, dz, dy, dx): a lane's 4 accumulator registers + the lane 16 further hold one
 //    window, pool2 is a max3 tree and one ds_swizzle; the pooled 56 x 128 tile goes through LDS for 16-byte stores.
+//    (The stores sit in the same vmcnt queue as the DMA: the first two counted waits of the next tile also wait for
+//    them -- conservative, never early.)
 //  * schedule: the two-group staggered loop of igemm_wide.hip.h (waves 0-3 / 4-7, partners on a SIMD, half a step
 //    apart: LOAD = fragment reads + DMA issue + counted wait, COMPUTE = 28 MFMAs), waves 4 (M) x 2 (N), 112 x 64 each.
 #pragma once
@@ -48,9 +50,11 @@ constexpr int C2_PLANE_STRIDE = C2_PLANE_BYTES + 256;
 constexpr int C2_BRING_OFF = 99328;                     // 4 plane buffers end at 3*24832 + 32 + 24576 = 99 104
 constexpr int C2_BSLOT = 128 * 64;                      // 8 KB: 128 filter rows x 32 K elements
 constexpr int C2_NSLOT = 4, C2_AHEAD = 3;
-constexpr int C2_SMEM = C2_BRING_OFF + C2_NSLOT * C2_BSLOT;     // 132 096
-constexpr int C2_STG_LD = 128 + 4;                      // staged pooled tile: 56 x 132 floats over the filter ring
-static_assert(56 * C2_STG_LD * 4 <= C2_NSLOT * C2_BSLOT, "pooled tile fits the ring");
+constexpr int C2_STG_OFF = C2_BRING_OFF + C2_NSLOT * C2_BSLOT;  // 132 096
+constexpr int C2_STG_LD = 128 + 4;                      // staged pooled tile: 56 x 132 floats, an area of its own (the
+                                                        // filter ring keeps running across tiles)
+constexpr int C2_SMEM = C2_STG_OFF + 56 * C2_STG_LD * 4;        // 161 664
+static_assert(C2_SMEM <= 160 * 1024, "LDS budget");
 constexpr int C2_TILES_PER_WINDOW = 8 * 14;
 constexpr int C2_IN_PLANE = 58 * 58 * 64, C2_IN_IMG = 18 * C2_IN_PLANE;      // elements
 constexpr int C2_OUT_ROW = 30 * 128, C2_OUT_PLANE = 30 * C2_OUT_ROW, C2_OUT_IMG = 10 * C2_OUT_PLANE;
@@ -121,6 +125,25 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
   }
   const unsigned b_addr = lds0 + C2_BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
 
+  const int cg = tid & 15;                                    // epilogue: this thread's 8 output channels
+  float b8[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) b8[q] = p.bias[cg * 8 + q];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
+  // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod 54) and the last sweep of a
+  // tile fetches planes 0, 1 of the next one. ----
+  {
+    const int tile0 = tile_of(t_seq);
+    dma_plane(plane_src(tile0, 0, 0), 0);
+    dma_plane(plane_src(tile0, 0, 1), 1);
+    dma_b(0, 0, 0);
+    dma_b(1, 0, 1);
+    dma_b(2, 0, 2);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // planes 0, 1 and slab 0 landed
+    __builtin_amdgcn_s_barrier();
+  }
+  int slot = 0;
   while (true) {
     const int tile = tile_of(t_seq);
     const int t_next = t_seq + gridDim.x;
@@ -132,21 +155,8 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
     for (int i = 0; i < 7; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: planes 0, 1 of the first sweep (the first tile only: later tiles find them prefetched), filter slabs
-    // of steps 0 .. 2 ----
-    if (t_seq == (int)blockIdx.x) {
-      dma_plane(plane_src(tile, 0, 0), 0);
-      dma_plane(plane_src(tile, 0, 1), 1);
-    }
-    dma_b(0, 0, 0);
-    dma_b(1, 0, 1);
-    dma_b(2, 0, 2);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // planes 0, 1 and slab 0 landed
-    __builtin_amdgcn_s_barrier();
     if (group_b) __builtin_amdgcn_s_barrier();               // run one half-step behind group A
 
-    int slot = 0;
     // one group of 9 taps (ky, kx) of plane offset kz, K steps s0 .. s0 + 8 of the tile; NPL plane fetches (3
     // instructions per wave each) are issued in its first LOAD phase
     auto tap_group = [&](auto NPL_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb) {
@@ -189,8 +199,7 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
           if (NPL >= 2) dma_plane(pl_b, kb);
         }
         {
-          // filter slab of step s + 3 (wraps into the next tile's steps 0 .. 2 at the end: re-fetched by its prologue,
-          // harmless and uniform)
+          // filter slab of step s + 3 (at the end of a tile: steps 0 .. 2 of the next one)
           int s3 = s + C2_AHEAD;
           if (s3 >= 54) s3 -= 54;
           const int cc3 = s3 >= 27 ? 1 : 0;
@@ -234,12 +243,10 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
       tap_group(I1{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0);
       tap_group(I1{}, cc, 2, plane_src(ntile, ncc, 1), 1, nullptr, 0);
     }
-    if (!group_b) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the wrapped slabs, and the next tile's planes 0, 1
-    __syncthreads();
+    if (!group_b) __builtin_amdgcn_s_barrier();               // the groups are level again
 
     // ---- epilogue: pool2 in registers, pooled tile through LDS (over the filter ring), bias + ReLU, 16-byte stores ----
-    float* stg = (float*)(c2_smem + C2_BRING_OFF);
+    float* stg = (float*)(c2_smem + C2_STG_OFF);
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
@@ -249,15 +256,12 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
         const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
         if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C2_STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
       }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: __syncthreads() would also drain the look-ahead DMA
+    __builtin_amdgcn_s_barrier();
     {
       const int n = tile / C2_TILES_PER_WINDOW, r = tile - n * C2_TILES_PER_WINDOW;
       const int zp = r / 14, yp = r - zp * 14;
       bf16_t* obase = p.out + (long long)n * C2_OUT_IMG + (zp + 1) * C2_OUT_PLANE + (2 * yp + 1) * C2_OUT_ROW + 128;
-      const int cg = tid & 15;
-      float b8[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) b8[q] = p.bias[cg * 8 + q];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int w = (tid >> 4) + 32 * k;                    // pooling window 0 .. 55
@@ -274,9 +278,11 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
         }
       }
     }
-    if (!has_next) break;
-    __syncthreads();                                           // staging read before the ring is refilled
-    t_seq = t_next;
+    if (!has_next) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the look-ahead DMA lands before the LDS is released
+      break;
+    }
+    t_seq = t_next;                                            // (the K loop's barriers separate this tile's staging reads from the next one's writes)
   }
 }
 
