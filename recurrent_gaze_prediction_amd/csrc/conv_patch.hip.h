@@ -1,5 +1,7 @@
-// C3D conv2a (3x3x3, 64->128, pad 1) + bias + ReLU + pool2 (2x2x2 max) for gfx950, bf16, inference.
-// Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:67-107.
+// C3D conv2a (3x3x3, 64->128) and conv3b (256->256), pad 1, + bias + ReLU + 2x2x2 max-pool for gfx950, bf16, inference.
+// Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:67-107 (conv2a, pool2), 133-173 (conv3b, pool3).
+// The text below describes conv2a; conv3b is the same kernel at 28 x 28 x 8 positions, 8 channel sweeps of 32, tiles of
+// 2 x 14 pooling windows x 256 channels (waves 2 (M) x 4 (N)), plane slabs of 6 x 30 pixels and 16 KB filter slabs.
 //
 // Why a kernel of its own: conv2a is the largest layer of the stack (22.7 of 78.8 TFLOP per 1024 windows) and the one
 // the general implicit-GEMM tile serves worst.  With N = 128 only the A tile can grow, and the A operand -- one
@@ -36,50 +38,67 @@
 
 namespace rgp {
 
-struct Conv2aParams {
-  const bf16_t* in;     // act1 [n][18][58][58][64]
-  const bf16_t* wp;     // packed filter [128][1728], K index = tap*64 + c
-  const float* bias;    // [128]
-  bf16_t* out;          // act2 [n][10][30][30][128]
+struct ConvPatchParams {
+  const bf16_t* in;     // [n][D+2][HW+2][HW+2][CIN] halo-padded
+  const bf16_t* wp;     // packed filter [NOUT][27*CIN], K index = ((c / 64) * 27 + tap) * 64 + c % 64
+  const float* bias;    // [NOUT]
+  bf16_t* out;          // [n][D/2+2][HW/2+2][HW/2+2][NOUT] halo-padded
   int n_windows;
 };
 
-constexpr int C2_PLANE_PIX = 384;                       // pixels fetched per plane slab (348 used)
-constexpr int C2_PLANE_BYTES = C2_PLANE_PIX * 64;       // 24 576
-constexpr int C2_PLANE_STRIDE = C2_PLANE_BYTES + 256;
-constexpr int C2_BRING_OFF = 99328;                     // 4 plane buffers end at 3*24832 + 32 + 24576 = 99 104
-constexpr int C2_BSLOT = 128 * 64;                      // 8 KB: 128 filter rows x 32 K elements
-constexpr int C2_NSLOT = 4, C2_AHEAD = 3;
-constexpr int C2_STG_OFF = C2_BRING_OFF + C2_NSLOT * C2_BSLOT;  // 132 096
-constexpr int C2_STG_LD = 128 + 4;                      // staged pooled tile: 56 x 132 floats, an area of its own (the
-                                                        // filter ring keeps running across tiles)
-constexpr int C2_SMEM = C2_STG_OFF + 56 * C2_STG_LD * 4;        // 161 664
-static_assert(C2_SMEM <= 160 * 1024, "LDS budget");
-constexpr int C2_TILES_PER_WINDOW = 8 * 14;
-constexpr int C2_IN_PLANE = 58 * 58 * 64, C2_IN_IMG = 18 * C2_IN_PLANE;      // elements
-constexpr int C2_OUT_ROW = 30 * 128, C2_OUT_PLANE = 30 * C2_OUT_ROW, C2_OUT_IMG = 10 * C2_OUT_PLANE;
+template <int CIN, int NOUT, int HW, int DEPTH> struct PatchCfg {
+  static constexpr int WP = HW + 2;                       // padded row: 58 / 30 pixels
+  static constexpr int XPN = HW / 2;                      // pooling windows per pooled row: 28 / 14
+  static constexpr int NCC = CIN / 32;                    // channel sweeps: 2 / 8
+  static constexpr int WIN = 2 * XPN;                     // pooling windows per tile: 56 / 28
+  static constexpr int WMW = WIN / 14, WNW = 8 / WMW;     // waves along M (14 windows = 7 m-tiles each) and N
+  static constexpr int PPW = (6 * WP + 127) / 128;        // plane-slab DMA instructions per wave: 3 / 2
+  static constexpr int PLANE_PIX = PPW * 128;             // pixels fetched per slab: 384 / 256 (348 / 180 used)
+  static constexpr int PLANE_BYTES = PLANE_PIX * 64, PLANE_STRIDE = PLANE_BYTES + 256;
+  static constexpr int BRING_OFF = (3 * PLANE_STRIDE + 32 + PLANE_BYTES + 1023) / 1024 * 1024;
+  static constexpr int BPW = NOUT / 128;                  // filter-slab DMA instructions per wave and step: 1 / 2
+  static constexpr int BSLOT = NOUT * 64;                 // 8 / 16 KB: NOUT filter rows x 32 K elements
+  static constexpr int NSLOT = 4, AHEAD = 3;
+  static constexpr int STG_OFF = BRING_OFF + NSLOT * BSLOT;
+  static constexpr int STG_LD = NOUT + 4;                 // staged pooled tile [WIN][NOUT + 4] floats, an area of its own
+                                                          // (the filter ring keeps running across tiles)
+  static constexpr int SMEM = STG_OFF + WIN * STG_LD * 4; // 161 664 / 161 216
+  static constexpr int NSTEP = NCC * 27;
+  static constexpr int YT = HW / 4;                       // tiles per pooled plane
+  static constexpr int TILES_PER_WINDOW = (DEPTH / 2) * YT;
+  static constexpr int K = 27 * CIN;
+  static constexpr int IN_ROW = WP * CIN, IN_PLANE = WP * IN_ROW, IN_IMG = (DEPTH + 2) * IN_PLANE;      // elements
+  static constexpr int OUT_ROW = (HW / 2 + 2) * NOUT, OUT_PLANE = (HW / 2 + 2) * OUT_ROW, OUT_IMG = (DEPTH / 2 + 2) * OUT_PLANE;
+  static constexpr int CGN = NOUT / 8;                    // epilogue: 8-channel groups
+  static_assert(WNW * 64 == NOUT && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0, "tile shape");
+  static_assert((WP * 64) % 256 == 128, "row pitch = 128 (mod 256): the bank argument of the header");
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  static_assert(WIN * CGN == 2 * 448, "epilogue: two items per thread (448 of the 512 threads)");
+};
 
 template <int OFF>
-static __device__ __forceinline__ f32x4 c2_lds_read128(unsigned addr) {
+static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
   f32x4 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
-static __device__ __forceinline__ unsigned c2_plane_base(int k) { return (unsigned)(k * C2_PLANE_STRIDE + 32 * (k & 1)); }
 
-static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Conv2aParams p) {
-  extern __shared__ __attribute__((aligned(16))) char c2_smem[];
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)c2_smem;
+template <int CIN, int NOUT, int HW, int DEPTH>
+static __global__ __launch_bounds__(512) void conv_patch_pool8_bf16_kernel(const ConvPatchParams p) {
+  using C = PatchCfg<CIN, NOUT, HW, DEPTH>;
+  extern __shared__ __attribute__((aligned(16))) char cp_smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cp_smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / C::WNW, wn = wave % C::WNW;
   const bool group_b = wave >= 4;
   const int frow = lane & 15, fk = lane >> 4;
+  auto plane_base = [](int k) { return (unsigned)(k * C::PLANE_STRIDE + 32 * (k & 1)); };
 
   // persistent tile walk: XCD x (workgroup id & 7) owns a contiguous range of tiles (neighbouring tiles share halo rows
   // and planes: one L2 serves them)
-  const int nt = p.n_windows * C2_TILES_PER_WINDOW;
+  const int nt = p.n_windows * C::TILES_PER_WINDOW;
   auto tile_of = [&](int t) {
     const int q = nt >> 3, r = nt & 7, x = t & 7, y = t >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
@@ -87,30 +106,34 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
   int t_seq = blockIdx.x;
   if (t_seq >= nt) return;
 
-  // source of plane k of (tile, channel half): element offset into `in`
+  // source of plane k of (tile, channel sweep cc)
   auto plane_src = [&](int tile, int cc, int k) -> const char* {
-    const int n = tile / C2_TILES_PER_WINDOW, r = tile - n * C2_TILES_PER_WINDOW;
-    const int zp = r / 14, yp = r - zp * 14;
-    return (const char*)(p.in + (long long)n * C2_IN_IMG + (long long)(2 * zp + k) * C2_IN_PLANE + (4 * yp) * (58 * 64) + cc * 32);
+    const int n = tile / C::TILES_PER_WINDOW, r = tile - n * C::TILES_PER_WINDOW;
+    const int zp = r / C::YT, yp = r - zp * C::YT;
+    return (const char*)(p.in + (long long)n * C::IN_IMG + (long long)(2 * zp + k) * C::IN_PLANE + (4 * yp) * C::IN_ROW + cc * 32);
   };
-  // this wave's 3 of the 24 DMA instructions of a plane: 16 pixels x 64 B each
+  // this wave's PPW of a plane slab's DMA instructions: 16 pixels x 64 B each
   const int dpix = lane >> 2, dchk = lane & 3;
   auto dma_plane = [&](const char* src, int k) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int j = wave * 3 + u;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 16 + dpix) * 128 + dchk * 16),
-                                       (__attribute__((address_space(3))) void*)(c2_smem + c2_plane_base(k) + j * 1024), 16, 0, 0);
+    for (int u = 0; u < C::PPW; ++u) {
+      const int j = wave * C::PPW + u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 16 + dpix) * (CIN * 2) + dchk * 16),
+                                       (__attribute__((address_space(3))) void*)(cp_smem + plane_base(k) + j * 1024), 16, 0, 0);
     }
   };
-  // filter slab of K step (cc, tap): this wave's 1 of 8 instructions (16 filter rows x 64 B), chunk-swizzled like
+  // filter slab of K step (cc, tap): this wave's BPW of its 1-KB blocks (16 filter rows x 64 B), chunk-swizzled like
   // igemm_wide.hip.h (physical chunk c of row r holds logical chunk c ^ ((-(r >> 2)) & 3))
   const int brow = lane >> 2;
   const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
-  const char* b_src = (const char*)(p.wp + (long long)(wave * 16 + brow) * 1728) + bchk * 16;
+  const char* b_src = (const char*)(p.wp + (long long)(wave * C::BPW * 16 + brow) * C::K) + bchk * 16;
   auto dma_b = [&](int slot, int cc, int tap) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (tap * 2 + cc) * 64),
-                                     (__attribute__((address_space(3))) void*)(c2_smem + C2_BRING_OFF + slot * C2_BSLOT + wave * 1024), 16, 0, 0);
+    const int koff = (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2;
+#pragma unroll
+    for (int u = 0; u < C::BPW; ++u)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (long long)u * 16 * C::K * 2 + koff),
+                                       (__attribute__((address_space(3))) void*)(cp_smem + C::BRING_OFF + slot * C::BSLOT + (wave * C::BPW + u) * 1024),
+                                       16, 0, 0);
   };
 
   // fragment addressing.  m-tile i of this wave = pooling windows 2 (7 wm + i), +1; row frow of it: window frow >> 3,
@@ -120,19 +143,19 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int w0 = 2 * (7 * wm + i);
-    const int ypl = w0 / 28, xp = w0 - ypl * 28 + r_ws;
-    rowaddr[i] = lds0 + ((2 * ypl + r_dy) * 58 + 2 * xp + r_dx) * 64 + fk * 16;
+    const int ypl = w0 / C::XPN, xp = w0 - ypl * C::XPN + r_ws;
+    rowaddr[i] = lds0 + ((2 * ypl + r_dy) * C::WP + 2 * xp + r_dx) * 64 + fk * 16;
   }
-  const unsigned b_addr = lds0 + C2_BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
+  const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
 
-  const int cg = tid & 15;                                    // epilogue: this thread's 8 output channels
+  const int cg = tid % C::CGN;                                // epilogue: this thread's 8 output channels
   float b8[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) b8[q] = p.bias[cg * 8 + q];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
-  // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod 54) and the last sweep of a
-  // tile fetches planes 0, 1 of the next one. ----
+  // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
+  // a tile fetches planes 0, 1 of the next one. ----
   {
     const int tile0 = tile_of(t_seq);
     dma_plane(plane_src(tile0, 0, 0), 0);
@@ -140,7 +163,7 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
     dma_b(0, 0, 0);
     dma_b(1, 0, 1);
     dma_b(2, 0, 2);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // planes 0, 1 and slab 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::BPW) : "memory");   // planes 0, 1 and slab 0 landed
     __builtin_amdgcn_s_barrier();
   }
   int slot = 0;
@@ -157,12 +180,12 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (group_b) __builtin_amdgcn_s_barrier();               // run one half-step behind group A
 
-    // one group of 9 taps (ky, kx) of plane offset kz, K steps s0 .. s0 + 8 of the tile; NPL plane fetches (3
+    // one group of 9 taps (ky, kx) of plane offset kz, K steps s0 .. s0 + 8 of the tile; NPL plane fetches (PPW
     // instructions per wave each) are issued in its first LOAD phase
     auto tap_group = [&](auto NPL_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb) {
       constexpr int NPL = decltype(NPL_)::value;
       unsigned ra[7];
-      const unsigned pb = r_dz ? c2_plane_base(kz + 1) : c2_plane_base(kz);
+      const unsigned pb = r_dz ? plane_base(kz + 1) : plane_base(kz);
 #pragma unroll
       for (int i = 0; i < 7; ++i) ra[i] = rowaddr[i] + pb;
       const int s0 = cc * 27 + kz * 9;
@@ -171,12 +194,12 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
         // ---------------- LOAD ----------------
         const int s = s0 + t9;
         f32x4 af[7], bf[4];
-        const unsigned bb = b_addr + slot * C2_BSLOT;
+        const unsigned bb = b_addr + slot * C::BSLOT;
         auto reads = [&](auto T9) {
           constexpr int t = decltype(T9)::value;
-          constexpr int imm = ((t / 3) * 58 + (t % 3)) * 64;
+          constexpr int imm = ((t / 3) * C::WP + (t % 3)) * 64;
 #pragma unroll
-          for (int i = 0; i < 7; ++i) af[i] = c2_lds_read128<imm>(ra[i]);
+          for (int i = 0; i < 7; ++i) af[i] = cp_lds_read128<imm>(ra[i]);
         };
         switch (t9) {
           case 0: reads(std::integral_constant<int, 0>{}); break;
@@ -189,10 +212,10 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
           case 7: reads(std::integral_constant<int, 7>{}); break;
           default: reads(std::integral_constant<int, 8>{}); break;
         }
-        bf[0] = c2_lds_read128<0>(bb);
-        bf[1] = c2_lds_read128<1024>(bb);
-        bf[2] = c2_lds_read128<2048>(bb);
-        bf[3] = c2_lds_read128<3072>(bb);
+        bf[0] = cp_lds_read128<0>(bb);
+        bf[1] = cp_lds_read128<1024>(bb);
+        bf[2] = cp_lds_read128<2048>(bb);
+        bf[3] = cp_lds_read128<3072>(bb);
         __builtin_amdgcn_sched_barrier(0);
         if (t9 == 0) {
           if (NPL >= 1) dma_plane(pl_a, ka);
@@ -200,18 +223,17 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
         }
         {
           // filter slab of step s + 3 (at the end of a tile: steps 0 .. 2 of the next one)
-          int s3 = s + C2_AHEAD;
-          if (s3 >= 54) s3 -= 54;
-          const int cc3 = s3 >= 27 ? 1 : 0;
-          int slot3 = slot + C2_AHEAD;
-          if (slot3 >= C2_NSLOT) slot3 -= C2_NSLOT;
+          int s3 = s + C::AHEAD;
+          if (s3 >= C::NSTEP) s3 -= C::NSTEP;
+          const int cc3 = s3 / 27;
+          int slot3 = slot + C::AHEAD;
+          if (slot3 >= C::NSLOT) slot3 -= C::NSLOT;
           dma_b(slot3, cc3, s3 - cc3 * 27);
         }
         __builtin_amdgcn_sched_barrier(0);
         // slab s+1 landed: younger are slabs s+2, s+3 and, in the two steps after a plane fetch, its instructions
-        if (t9 < 2 && NPL == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (t9 < 2 && NPL == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        if (t9 < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C::BPW + NPL * C::PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C::BPW) : "memory");
 #pragma unroll
         for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
@@ -229,24 +251,25 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        slot = slot + 1 == C2_NSLOT ? 0 : slot + 1;
+        slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
       }
     };
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
 #pragma clang loop unroll(disable)
-    for (int cc = 0; cc < 2; ++cc) {
-      // the sweep after this one: the other channel half of this tile, or the first half of the next tile
-      const int ntile = cc == 0 ? tile : tile_next;
-      const int ncc = cc ^ 1;
+    for (int cc = 0; cc < C::NCC; ++cc) {
+      // the sweep after this one: the next channel slice of this tile, or the first one of the next tile
+      const bool last = cc == C::NCC - 1;
+      const int ntile = last ? tile_next : tile;
+      const int ncc = last ? 0 : cc + 1;
       tap_group(I2{}, cc, 0, plane_src(tile, cc, 2), 2, plane_src(tile, cc, 3), 3);
       tap_group(I1{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0);
       tap_group(I1{}, cc, 2, plane_src(ntile, ncc, 1), 1, nullptr, 0);
     }
     if (!group_b) __builtin_amdgcn_s_barrier();               // the groups are level again
 
-    // ---- epilogue: pool2 in registers, pooled tile through LDS (over the filter ring), bias + ReLU, 16-byte stores ----
-    float* stg = (float*)(c2_smem + C2_STG_OFF);
+    // ---- epilogue: pool in registers, pooled tile through LDS, bias + ReLU, 16-byte stores ----
+    float* stg = (float*)(cp_smem + C::STG_OFF);
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
@@ -254,27 +277,27 @@ static __global__ __launch_bounds__(512) void conv2a_patch_bf16_kernel(const Con
         const f32x4 c = acc[i][j];
         const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
         const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
-        if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C2_STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
+        if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: __syncthreads() would also drain the look-ahead DMA
     __builtin_amdgcn_s_barrier();
     {
-      const int n = tile / C2_TILES_PER_WINDOW, r = tile - n * C2_TILES_PER_WINDOW;
-      const int zp = r / 14, yp = r - zp * 14;
-      bf16_t* obase = p.out + (long long)n * C2_OUT_IMG + (zp + 1) * C2_OUT_PLANE + (2 * yp + 1) * C2_OUT_ROW + 128;
+      const int n = tile / C::TILES_PER_WINDOW, r = tile - n * C::TILES_PER_WINDOW;
+      const int zp = r / C::YT, yp = r - zp * C::YT;
+      bf16_t* obase = p.out + (long long)n * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int w = (tid >> 4) + 32 * k;                    // pooling window 0 .. 55
-        if (w < 56) {
-          const float* src = stg + w * C2_STG_LD + cg * 8;
+        const int w = tid / C::CGN + (512 / C::CGN) * k;      // pooling window of the tile
+        if (w < C::WIN) {
+          const float* src = stg + w * C::STG_LD + cg * 8;
           const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
           const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           u32x4 o;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             o[q] = (unsigned)f2bf(fmaxf(v[2 * q] + b8[2 * q], 0.f)) | ((unsigned)f2bf(fmaxf(v[2 * q + 1] + b8[2 * q + 1], 0.f)) << 16);
-          const int ypl = w / 28, xp = w - ypl * 28;
-          *(u32x4*)(obase + ypl * C2_OUT_ROW + xp * 128 + cg * 8) = o;
+          const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
+          *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = o;
         }
       }
     }

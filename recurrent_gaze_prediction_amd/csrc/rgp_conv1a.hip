@@ -1,9 +1,9 @@
 // librgp_hip.so: launch of the dedicated bf16 conv1a + bias + ReLU + pool1 kernel (conv1a.hip.h).
 // A translation unit of its own because it is compiled with -fno-honor-nans (see the header comment of conv1a.hip.h);
-// the dedicated conv2a kernel (conv2a_patch.hip.h) lives here too.
+// the patch kernels of conv2a / conv3b (conv_patch.hip.h) live here too.
 #include "rgp_c3d_plan.h"
 #include "conv1a.hip.h"
-#include "conv2a_patch.hip.h"
+#include "conv_patch.hip.h"
 
 using namespace rgp;
 
@@ -40,18 +40,28 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video) {
   return launch(conv1a_pool_bf16_kernel<false, false>);
 }
 
-// bf16 inference conv2a + pool2 (conv2a_patch.hip.h); the training plan (arg-max codes) keeps the general kernel
-int run_conv2a_patch_bf16(rgp_c3d* c, int n, hipStream_t s) {
-  Conv2aParams p;
-  p.in = (const bf16_t*)(c->ws + c->act_off[1]);
-  p.wp = (const bf16_t*)(c->ws + c->L[1].w_off);
-  p.bias = c->bias[1];
-  p.out = (bf16_t*)(c->ws + c->act_off[2]);
+// bf16 inference conv2a + pool2 / conv3b + pool3 (conv_patch.hip.h); the training plan (arg-max codes) keeps the
+// general kernel
+template <int CIN, int NOUT, int HW, int DEPTH>
+static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  using Cfg = PatchCfg<CIN, NOUT, HW, DEPTH>;
+  ConvPatchParams p;
+  p.in = (const bf16_t*)(c->ws + c->act_off[layer]);
+  p.wp = (const bf16_t*)(c->ws + c->L[layer].w_off);
+  p.bias = c->bias[layer];
+  p.out = (bf16_t*)(c->ws + c->act_off[layer + 1]);
   p.n_windows = n;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
-  RGP_TRY(ensure_dyn_smem((const void*)conv2a_patch_bf16_kernel, C2_SMEM));
-  conv2a_patch_bf16_kernel<<<n_cu, 512, C2_SMEM, s>>>(p);
+  auto kern = conv_patch_pool8_bf16_kernel<CIN, NOUT, HW, DEPTH>;
+  RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
+  kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
+}
+
+int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  if (layer == 1) return run_conv_patch<64, 128, 56, 16>(c, layer, n, s);
+  if (layer == 3) return run_conv_patch<256, 256, 28, 8>(c, layer, n, s);
+  return set_err(RGP_EINVAL, "conv_patch: no kernel for layer %d", layer);
 }
