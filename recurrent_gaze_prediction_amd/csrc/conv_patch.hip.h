@@ -46,7 +46,7 @@ struct ConvPatchParams {
   int n_windows;
 };
 
-template <int CIN, int NOUT, int HW, int DEPTH> struct PatchCfg {
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCfg {
   static constexpr int WP = HW + 2;                       // padded row: 58 / 30 pixels
   static constexpr int XPN = HW / 2;                      // pooling windows per pooled row: 28 / 14
   static constexpr int NCC = CIN / 32;                    // channel sweeps: 2 / 8
@@ -62,13 +62,14 @@ template <int CIN, int NOUT, int HW, int DEPTH> struct PatchCfg {
   static constexpr int STG_OFF = BRING_OFF + NSLOT * BSLOT;
   static constexpr int STG_LD = NOUT + 4;                 // staged pooled tile [WIN][NOUT + 4] floats, an area of its own
                                                           // (the filter ring keeps running across tiles)
-  static constexpr int SMEM = STG_OFF + WIN * STG_LD * 4; // 161 664 / 161 216
+  static constexpr int SMEM = STG_OFF + (POOL ? WIN * STG_LD * 4 : 0); // 161 664 / 161 216 (pooled layers)
   static constexpr int NSTEP = NCC * 27;
   static constexpr int YT = HW / 4;                       // tiles per pooled plane
   static constexpr int TILES_PER_WINDOW = (DEPTH / 2) * YT;
   static constexpr int K = 27 * CIN;
   static constexpr int IN_ROW = WP * CIN, IN_PLANE = WP * IN_ROW, IN_IMG = (DEPTH + 2) * IN_PLANE;      // elements
-  static constexpr int OUT_ROW = (HW / 2 + 2) * NOUT, OUT_PLANE = (HW / 2 + 2) * OUT_ROW, OUT_IMG = (DEPTH / 2 + 2) * OUT_PLANE;
+  static constexpr int OW = POOL ? HW / 2 : HW, OD = POOL ? DEPTH / 2 : DEPTH;   // output extent
+  static constexpr int OUT_ROW = (OW + 2) * NOUT, OUT_PLANE = (OW + 2) * OUT_ROW, OUT_IMG = (OD + 2) * OUT_PLANE;
   static constexpr int CGN = NOUT / 8;                    // epilogue: 8-channel groups
   static_assert(WNW * 64 == NOUT && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0, "tile shape");
   static_assert((WP * 64) % 256 == 128, "row pitch = 128 (mod 256): the bank argument of the header");
@@ -83,9 +84,13 @@ static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
   return v;
 }
 
-template <int CIN, int NOUT, int HW, int DEPTH>
-static __global__ __launch_bounds__(512) void conv_patch_pool8_bf16_kernel(const ConvPatchParams p) {
-  using C = PatchCfg<CIN, NOUT, HW, DEPTH>;
+// POOL: 2x2x2 max-pool epilogue (conv2a, conv3b).  !POOL (conv3a): the same tiles -- the row order (2x2x2 blocks of
+// positions) is immaterial to a convolution -- stored un-pooled; MFMA column 16 j + c of a wave then carries channel
+// 64 wn + 4 c + j (the filter slab is fetched in that row order), so a lane holds 4 adjacent channels of a position and
+// stores 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL>
+static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvPatchParams p) {
+  using C = PatchCfg<CIN, NOUT, HW, DEPTH, POOL>;
   extern __shared__ __attribute__((aligned(16))) char cp_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cp_smem;
   const int tid = threadIdx.x;
@@ -126,12 +131,16 @@ static __global__ __launch_bounds__(512) void conv_patch_pool8_bf16_kernel(const
   // igemm_wide.hip.h (physical chunk c of row r holds logical chunk c ^ ((-(r >> 2)) & 3))
   const int brow = lane >> 2;
   const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
-  const char* b_src = (const char*)(p.wp + (long long)(wave * C::BPW * 16 + brow) * C::K) + bchk * 16;
+  // filter row (output channel) behind row brow of 1-KB block blk: blk * 16 + brow, or (!POOL) 64 (blk >> 2) + 4 brow + (blk & 3)
+  auto b_row = [&](int blk) { return POOL ? blk * 16 + brow : (blk >> 2) * 64 + brow * 4 + (blk & 3); };
+  const char* b_src[C::BPW];
+#pragma unroll
+  for (int u = 0; u < C::BPW; ++u) b_src[u] = (const char*)(p.wp + (long long)b_row(wave * C::BPW + u) * C::K) + bchk * 16;
   auto dma_b = [&](int slot, int cc, int tap) {
     const int koff = (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2;
 #pragma unroll
     for (int u = 0; u < C::BPW; ++u)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (long long)u * 16 * C::K * 2 + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[u] + koff),
                                        (__attribute__((address_space(3))) void*)(cp_smem + C::BRING_OFF + slot * C::BSLOT + (wave * C::BPW + u) * 1024),
                                        16, 0, 0);
   };
@@ -148,10 +157,10 @@ static __global__ __launch_bounds__(512) void conv_patch_pool8_bf16_kernel(const
   }
   const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
 
-  const int cg = tid % C::CGN;                                // epilogue: this thread's 8 output channels
+  const int cg = tid % C::CGN;                                // POOL epilogue: this thread's 8 output channels
   float b8[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) b8[q] = p.bias[cg * 8 + q];
+  for (int q = 0; q < 8; ++q) b8[q] = POOL ? p.bias[cg * 8 + q] : (q < 4 ? p.bias[wn * 64 + frow * 4 + q] : 0.f);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -268,23 +277,23 @@ static __global__ __launch_bounds__(512) void conv_patch_pool8_bf16_kernel(const
     }
     if (!group_b) __builtin_amdgcn_s_barrier();               // the groups are level again
 
-    // ---- epilogue: pool in registers, pooled tile through LDS, bias + ReLU, 16-byte stores ----
-    float* stg = (float*)(cp_smem + C::STG_OFF);
+    const int tn = tile / C::TILES_PER_WINDOW, tr = tile - tn * C::TILES_PER_WINDOW;
+    const int zp = tr / C::YT, yp = tr - zp * C::YT;
+    if constexpr (POOL) {
+      // ---- epilogue: pool in registers, pooled tile through LDS, bias + ReLU, 16-byte stores ----
+      float* stg = (float*)(cp_smem + C::STG_OFF);
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
+      for (int i = 0; i < 7; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 c = acc[i][j];
-        const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
-        const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
-        if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: __syncthreads() would also drain the look-ahead DMA
-    __builtin_amdgcn_s_barrier();
-    {
-      const int n = tile / C::TILES_PER_WINDOW, r = tile - n * C::TILES_PER_WINDOW;
-      const int zp = r / C::YT, yp = r - zp * C::YT;
-      bf16_t* obase = p.out + (long long)n * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 c = acc[i][j];
+          const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+          const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
+          if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
+      __builtin_amdgcn_s_barrier();
+      bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int w = tid / C::CGN + (512 / C::CGN) * k;      // pooling window of the tile
@@ -298,6 +307,24 @@ static __global__ __launch_bounds__(512) void conv_patch_pool8_bf16_kernel(const
             o[q] = (unsigned)f2bf(fmaxf(v[2 * q] + b8[2 * q], 0.f)) | ((unsigned)f2bf(fmaxf(v[2 * q + 1] + b8[2 * q + 1], 0.f)) << 16);
           const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
           *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = o;
+        }
+      }
+    } else {
+      // ---- epilogue: bias + ReLU, 8-byte stores from registers.  Register e of accumulator (i, j): row 4 fk + e of
+      // m-tile i = window 2 (7 wm + i) + (fk >> 1), dz = fk & 1, dy = e >> 1, dx = e & 1; channel 64 wn + 4 frow + j ----
+      bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (2 * zp + 1 + (fk & 1)) * C::OUT_PLANE + (4 * yp + 1) * C::OUT_ROW + NOUT +
+                      wn * 64 + frow * 4;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int w = 2 * (7 * wm + i) + (fk >> 1);
+        const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
+        bf16_t* ow = obase + (2 * ypl) * C::OUT_ROW + (2 * xp) * NOUT;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint2 o;
+          o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b8[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b8[1], 0.f)) << 16);
+          o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b8[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b8[3], 0.f)) << 16);
+          *(uint2*)(ow + (e >> 1) * C::OUT_ROW + (e & 1) * NOUT) = o;
         }
       }
     }

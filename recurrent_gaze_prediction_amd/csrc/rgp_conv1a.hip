@@ -40,11 +40,11 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video) {
   return launch(conv1a_pool_bf16_kernel<false, false>);
 }
 
-// bf16 inference conv2a + pool2 / conv3b + pool3 (conv_patch.hip.h); the training plan (arg-max codes) keeps the
+// bf16 inference conv2a + pool2 / conv3a / conv3b + pool3 (conv_patch.hip.h); the training plan (arg-max codes) keeps the
 // general kernel
-template <int CIN, int NOUT, int HW, int DEPTH>
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL>
 static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
-  using Cfg = PatchCfg<CIN, NOUT, HW, DEPTH>;
+  using Cfg = PatchCfg<CIN, NOUT, HW, DEPTH, POOL>;
   ConvPatchParams p;
   p.in = (const bf16_t*)(c->ws + c->act_off[layer]);
   p.wp = (const bf16_t*)(c->ws + c->L[layer].w_off);
@@ -53,7 +53,7 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.n_windows = n;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
-  auto kern = conv_patch_pool8_bf16_kernel<CIN, NOUT, HW, DEPTH>;
+  auto kern = conv_patch_bf16_kernel<CIN, NOUT, HW, DEPTH, POOL>;
   RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
   kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
@@ -61,7 +61,8 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
 }
 
 int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
-  if (layer == 1) return run_conv_patch<64, 128, 56, 16>(c, layer, n, s);
-  if (layer == 3) return run_conv_patch<256, 256, 28, 8>(c, layer, n, s);
+  if (layer == 1) return run_conv_patch<64, 128, 56, 16, true>(c, layer, n, s);
+  if (layer == 2) return run_conv_patch<128, 256, 28, 8, false>(c, layer, n, s);
+  if (layer == 3) return run_conv_patch<256, 256, 28, 8, true>(c, layer, n, s);
   return set_err(RGP_EINVAL, "conv_patch: no kernel for layer %d", layer);
 }
