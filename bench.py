@@ -42,10 +42,13 @@ C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
 C3D_POOL = {'conv1a': 4, 'conv2a': 8, 'conv3a': 1, 'conv3b': 8, 'conv4a': 1, 'conv4b': 8, 'conv5a': 1, 'conv5b': 1}
 
 
-def c3d_kernel_group(name, n_windows, dtype='bf16'):
+def c3d_kernel_group(name, n_windows, dtype='bf16', train=False):
+    """Kernel (template instance) that runs a conv layer: the dispatch of rgp_c3d.hip / rgp_host.h restated."""
     ci, co, d, h = next((ci, co, d, h) for nm, ci, co, d, h in C3D_LAYERS if nm == name)
     if name == 'conv1a' and dtype == 'bf16':
         return 'conv1a_pool_bf16_kernel'
+    if dtype == 'bf16' and name in ('conv2a', 'conv3a', 'conv3b'):                    # conv_patch.hip.h
+        return 'conv_patch_bf16_kernel<%d,%d,%d,%d,%s>' % (ci, co, h, d, 'pool8' if C3D_POOL[name] == 8 else 'pool1')
     rows = n_windows * d * h * h
     pool = 'pool%d' % C3D_POOL[name]
     if dtype == 'bf16' and co % 256 == 0 and -(-rows // 256) * (co // 256) >= 1024:
@@ -218,7 +221,7 @@ def main():
             groups = {}
             for name, _, _, _, _ in C3D_LAYERS:
                 ms, calls = cprof[name]
-                grp = groups.setdefault(c3d_kernel_group(name, min(args.c3d_chunk, F), args.dtype), [0.0, 0.0, 0])
+                grp = groups.setdefault(c3d_kernel_group(name, min(args.c3d_chunk, F), args.dtype, train=ft is not None), [0.0, 0.0, 0])
                 grp[0] += ms
                 grp[1] += C3D_FLOPS[name] * F * args.steps          # flops executed in the timed region
                 grp[2] += calls

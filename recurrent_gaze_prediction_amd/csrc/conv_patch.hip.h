@@ -43,6 +43,7 @@ struct ConvPatchParams {
   const bf16_t* wp;     // packed filter [NOUT][27*CIN], K index = ((c / 64) * 27 + tap) * 64 + c % 64
   const float* bias;    // [NOUT]
   bf16_t* out;          // [n][D/2+2][HW/2+2][HW/2+2][NOUT] halo-padded
+  unsigned char* argmax;  // pooled layers, training plans: [n][D/2][HW/2][HW/2][NOUT] index (dz*4 + dy*2 + dx) of the first maximum
   int n_windows;
 };
 
@@ -60,9 +61,11 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static constexpr int BSLOT = NOUT * 64;                 // 8 / 16 KB: NOUT filter rows x 32 K elements
   static constexpr int NSLOT = 4, AHEAD = 3;
   static constexpr int STG_OFF = BRING_OFF + NSLOT * BSLOT;
-  static constexpr int STG_LD = NOUT + 4;                 // staged pooled tile [WIN][NOUT + 4] floats, an area of its own
-                                                          // (the filter ring keeps running across tiles)
-  static constexpr int SMEM = STG_OFF + (POOL ? WIN * STG_LD * 4 : 0); // 161 664 / 161 216 (pooled layers)
+  // staged pooled tile (bias + ReLU applied, bf16) [WIN][NOUT + 8] and its arg-max codes [WIN][NOUT + 8] bytes: an area of
+  // its own (the filter ring keeps running across tiles)
+  static constexpr int STG_LD = NOUT + 8;
+  static constexpr int STGA_OFF = STG_OFF + WIN * STG_LD * 2;
+  static constexpr int SMEM = POOL ? STGA_OFF + WIN * STG_LD : STG_OFF;     // 154 944 / 154 272 (pooled layers)
   static constexpr int NSTEP = NCC * 27;
   static constexpr int YT = HW / 4;                       // tiles per pooled plane
   static constexpr int TILES_PER_WINDOW = (DEPTH / 2) * YT;
@@ -75,6 +78,7 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static_assert((WP * 64) % 256 == 128, "row pitch = 128 (mod 256): the bank argument of the header");
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(WIN * CGN == 2 * 448, "epilogue: two items per thread (448 of the 512 threads)");
+  static_assert((STG_LD * 2) % 16 == 0 && STG_LD % 8 == 0, "staging rows keep 16- / 8-byte alignment");
 };
 
 template <int OFF>
@@ -88,8 +92,9 @@ static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
 // positions) is immaterial to a convolution -- stored un-pooled; MFMA column 16 j + c of a wave then carries channel
 // 64 wn + 4 c + j (the filter slab is fetched in that row order), so a lane holds 4 adjacent channels of a position and
 // stores 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
-template <int CIN, int NOUT, int HW, int DEPTH, bool POOL>
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX = false>
 static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvPatchParams p) {
+  static_assert(POOL || !ARGMAX, "arg-max codes belong to the pooled layers");
   using C = PatchCfg<CIN, NOUT, HW, DEPTH, POOL>;
   extern __shared__ __attribute__((aligned(16))) char cp_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cp_smem;
@@ -157,10 +162,10 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   }
   const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
 
-  const int cg = tid % C::CGN;                                // POOL epilogue: this thread's 8 output channels
-  float b8[8];
+  const int cg = tid % C::CGN;                                // POOL epilogue, store pass: this thread's 8 output channels
+  float b4[4];                                                // bias of this lane's 4 MFMA columns
 #pragma unroll
-  for (int q = 0; q < 8; ++q) b8[q] = POOL ? p.bias[cg * 8 + q] : (q < 4 ? p.bias[wn * 64 + frow * 4 + q] : 0.f);
+  for (int q = 0; q < 4; ++q) b4[q] = p.bias[POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -280,33 +285,45 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     const int tn = tile / C::TILES_PER_WINDOW, tr = tile - tn * C::TILES_PER_WINDOW;
     const int zp = tr / C::YT, yp = tr - zp * C::YT;
     if constexpr (POOL) {
-      // ---- epilogue: pool in registers, pooled tile through LDS, bias + ReLU, 16-byte stores ----
-      float* stg = (float*)(cp_smem + C::STG_OFF);
+      // ---- epilogue: pool in registers (a lane holds the 4 members of a window with its dz, lane ^ 16 the other 4),
+      // bias + ReLU, pooled bf16 tile (and arg-max codes) through LDS, 16-byte (8-byte) stores ----
+      bf16_t* stg = (bf16_t*)(cp_smem + C::STG_OFF);
+      unsigned char* stga = (unsigned char*)(cp_smem + C::STGA_OFF);
 #pragma unroll
       for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 c = acc[i][j];
-          const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
-          const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
-          if ((fk & 1) == 0) stg[(2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + j * 16 + frow] = fmaxf(x, y);
+          const int so = (2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + j * 16 + frow;
+          if constexpr (ARGMAX) {
+            float best = c[0];
+            int idx = 0;
+            if (c[1] > best) { best = c[1]; idx = 1; }
+            if (c[2] > best) { best = c[2]; idx = 2; }
+            if (c[3] > best) { best = c[3]; idx = 3; }
+            const float ob = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, best), 0x401F));   // lane ^ 16
+            const int oi = __builtin_amdgcn_ds_swizzle(idx, 0x401F);
+            if ((fk & 1) == 0) {                               // this lane: dz = 0 (members 0 .. 3), the other: dz = 1
+              stg[so] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
+              stga[so] = (unsigned char)(ob > best ? oi + 4 : idx);
+            }
+          } else {
+            const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+            const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+            if ((fk & 1) == 0) stg[so] = f2bf(fmaxf(fmaxf(x, y) + b4[j], 0.f));
+          }
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
       __builtin_amdgcn_s_barrier();
       bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
+      unsigned char* abase = ARGMAX ? p.argmax + (((long long)tn * (DEPTH / 2) + zp) * (HW / 2) + 2 * yp) * (long long)((HW / 2) * NOUT) : nullptr;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int w = tid / C::CGN + (512 / C::CGN) * k;      // pooling window of the tile
         if (w < C::WIN) {
-          const float* src = stg + w * C::STG_LD + cg * 8;
-          const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          u32x4 o;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            o[q] = (unsigned)f2bf(fmaxf(v[2 * q] + b8[2 * q], 0.f)) | ((unsigned)f2bf(fmaxf(v[2 * q + 1] + b8[2 * q + 1], 0.f)) << 16);
           const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
-          *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = o;
+          *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = *(const u32x4*)(stg + w * C::STG_LD + cg * 8);
+          if constexpr (ARGMAX) *(uint2*)(abase + (ypl * (HW / 2) + xp) * NOUT + cg * 8) = *(const uint2*)(stga + w * C::STG_LD + cg * 8);
         }
       }
     } else {
@@ -322,8 +339,8 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           uint2 o;
-          o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b8[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b8[1], 0.f)) << 16);
-          o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b8[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b8[3], 0.f)) << 16);
+          o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b4[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b4[1], 0.f)) << 16);
+          o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b4[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b4[3], 0.f)) << 16);
           *(uint2*)(ow + (e >> 1) * C::OUT_ROW + (e & 1) * NOUT) = o;
         }
       }

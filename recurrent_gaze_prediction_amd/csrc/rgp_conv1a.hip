@@ -40,9 +40,9 @@ int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video) {
   return launch(conv1a_pool_bf16_kernel<false, false>);
 }
 
-// bf16 inference conv2a + pool2 / conv3a / conv3b + pool3 (conv_patch.hip.h); the training plan (arg-max codes) keeps the
-// general kernel
-template <int CIN, int NOUT, int HW, int DEPTH, bool POOL>
+// bf16 conv2a + pool2 / conv3a / conv3b + pool3 (conv_patch.hip.h); a training plan records the arg-max codes of the
+// pooled layers
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX>
 static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   using Cfg = PatchCfg<CIN, NOUT, HW, DEPTH, POOL>;
   ConvPatchParams p;
@@ -50,10 +50,11 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.wp = (const bf16_t*)(c->ws + c->L[layer].w_off);
   p.bias = c->bias[layer];
   p.out = (bf16_t*)(c->ws + c->act_off[layer + 1]);
+  p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
   p.n_windows = n;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
-  auto kern = conv_patch_bf16_kernel<CIN, NOUT, HW, DEPTH, POOL>;
+  auto kern = conv_patch_bf16_kernel<CIN, NOUT, HW, DEPTH, POOL, ARGMAX>;
   RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
   kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
@@ -61,8 +62,8 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
 }
 
 int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
-  if (layer == 1) return run_conv_patch<64, 128, 56, 16, true>(c, layer, n, s);
-  if (layer == 2) return run_conv_patch<128, 256, 28, 8, false>(c, layer, n, s);
-  if (layer == 3) return run_conv_patch<256, 256, 28, 8, true>(c, layer, n, s);
+  if (layer == 1) return c->save ? run_conv_patch<64, 128, 56, 16, true, true>(c, layer, n, s) : run_conv_patch<64, 128, 56, 16, true, false>(c, layer, n, s);
+  if (layer == 2) return run_conv_patch<128, 256, 28, 8, false, false>(c, layer, n, s);
+  if (layer == 3) return c->save ? run_conv_patch<256, 256, 28, 8, true, true>(c, layer, n, s) : run_conv_patch<256, 256, 28, 8, true, false>(c, layer, n, s);
   return set_err(RGP_EINVAL, "conv_patch: no kernel for layer %d", layer);
 }
