@@ -4,6 +4,7 @@
 #include "rgp_c3d_plan.h"
 #include "conv1a.hip.h"
 #include "conv_patch.hip.h"
+#include "conv_patch14.hip.h"
 
 using namespace rgp;
 
@@ -61,7 +62,28 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   return RGP_OK;
 }
 
+template <int CIN, bool POOL, bool ARGMAX>
+static int run_conv_patch14(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  using Cfg = Patch14Cfg<CIN, POOL>;
+  ConvPatchParams p;
+  p.in = (const bf16_t*)(c->ws + c->act_off[layer]);
+  p.wp = (const bf16_t*)(c->ws + c->L[layer].w_off);
+  p.bias = c->bias[layer];
+  p.out = (bf16_t*)(c->ws + c->act_off[layer + 1]);
+  p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
+  p.n_windows = n;
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  auto kern = conv_patch14_bf16_kernel<CIN, POOL, ARGMAX>;
+  RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
+  kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  if (layer == 4) return run_conv_patch14<256, false, false>(c, layer, n, s);
+  if (layer == 5) return c->save ? run_conv_patch14<512, true, true>(c, layer, n, s) : run_conv_patch14<512, true, false>(c, layer, n, s);
   if (layer == 1) return c->save ? run_conv_patch<64, 128, 56, 16, true, true>(c, layer, n, s) : run_conv_patch<64, 128, 56, 16, true, false>(c, layer, n, s);
   if (layer == 2) return run_conv_patch<128, 256, 28, 8, false, false>(c, layer, n, s);
   if (layer == 3) return c->save ? run_conv_patch<256, 256, 28, 8, true, true>(c, layer, n, s) : run_conv_patch<256, 256, 28, 8, true, false>(c, layer, n, s);
