@@ -44,6 +44,7 @@ struct ConvPatchParams {
   const float* bias;    // [NOUT]
   bf16_t* out;          // [n][D/2+2][HW/2+2][HW/2+2][NOUT] halo-padded
   unsigned char* argmax;  // pooled layers, training plans: [n][D/2][HW/2][HW/2][NOUT] index (dz*4 + dy*2 + dx) of the first maximum
+  const bf16_t* mask;     // DGRAD kernels: forward activation in the layout of `out`; the result is kept where it is > 0
   int n_windows;
 };
 
@@ -92,9 +93,12 @@ static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
 // positions) is immaterial to a convolution -- stored un-pooled; MFMA column 16 j + c of a wave then carries channel
 // 64 wn + 4 c + j (the filter slab is fetched in that row order), so a lane holds 4 adjacent channels of a position and
 // stores 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
-template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX = false>
+// DGRAD (!POOL): the same convolution as the input gradient of a layer (in = dY before pooling, halo-padded; filter =
+// the rotated, in/out-swapped one of the backward plan): no bias, no ReLU, the result masked by the forward activation.
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX = false, bool DGRAD = false>
 static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvPatchParams p) {
   static_assert(POOL || !ARGMAX, "arg-max codes belong to the pooled layers");
+  static_assert(!POOL || !DGRAD, "the input gradient is an un-pooled convolution");
   using C = PatchCfg<CIN, NOUT, HW, DEPTH, POOL>;
   extern __shared__ __attribute__((aligned(16))) char cp_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cp_smem;
@@ -165,7 +169,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   const int cg = tid % C::CGN;                                // POOL epilogue, store pass: this thread's 8 output channels
   float b4[4];                                                // bias of this lane's 4 MFMA columns
 #pragma unroll
-  for (int q = 0; q < 4; ++q) b4[q] = p.bias[POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q];
+  for (int q = 0; q < 4; ++q) b4[q] = DGRAD ? 0.f : p.bias[POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -329,19 +333,27 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     } else {
       // ---- epilogue: bias + ReLU, 8-byte stores from registers.  Register e of accumulator (i, j): row 4 fk + e of
       // m-tile i = window 2 (7 wm + i) + (fk >> 1), dz = fk & 1, dy = e >> 1, dx = e & 1; channel 64 wn + 4 frow + j ----
-      bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (2 * zp + 1 + (fk & 1)) * C::OUT_PLANE + (4 * yp + 1) * C::OUT_ROW + NOUT +
-                      wn * 64 + frow * 4;
+      const long long obase = (long long)tn * C::OUT_IMG + (2 * zp + 1 + (fk & 1)) * C::OUT_PLANE + (4 * yp + 1) * C::OUT_ROW + NOUT + wn * 64 + frow * 4;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int w = 2 * (7 * wm + i) + (fk >> 1);
         const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
-        bf16_t* ow = obase + (2 * ypl) * C::OUT_ROW + (2 * xp) * NOUT;
+        const long long ow = obase + (2 * ypl) * C::OUT_ROW + (2 * xp) * NOUT;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          const long long oe = ow + (e >> 1) * C::OUT_ROW + (e & 1) * NOUT;
           uint2 o;
-          o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b4[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b4[1], 0.f)) << 16);
-          o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b4[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b4[3], 0.f)) << 16);
-          *(uint2*)(ow + (e >> 1) * C::OUT_ROW + (e & 1) * NOUT) = o;
+          if constexpr (DGRAD) {
+            const uint2 m = *(const uint2*)(p.mask + oe);
+            const float v0 = bf2f((bf16_t)(m.x & 0xffffu)) > 0.f ? acc[i][0][e] : 0.f, v1 = bf2f((bf16_t)(m.x >> 16)) > 0.f ? acc[i][1][e] : 0.f;
+            const float v2 = bf2f((bf16_t)(m.y & 0xffffu)) > 0.f ? acc[i][2][e] : 0.f, v3 = bf2f((bf16_t)(m.y >> 16)) > 0.f ? acc[i][3][e] : 0.f;
+            o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+            o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+          } else {
+            o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b4[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b4[1], 0.f)) << 16);
+            o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b4[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b4[3], 0.f)) << 16);
+          }
+          *(uint2*)(p.out + oe) = o;
         }
       }
     }

@@ -45,9 +45,10 @@ template <int CIN, bool POOL> struct Patch14Cfg {
   static_assert(LROW % 256 == 128, "row pitch = 128 (mod 256)");
 };
 
-template <int CIN, bool POOL, bool ARGMAX = false>
+template <int CIN, bool POOL, bool ARGMAX = false, bool DGRAD = false>
 static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const ConvPatchParams p) {
   static_assert(POOL || !ARGMAX, "arg-max codes belong to the pooled layer");
+  static_assert(!POOL || !DGRAD, "the input gradient is an un-pooled convolution");
   using C = Patch14Cfg<CIN, POOL>;
   extern __shared__ __attribute__((aligned(16))) char cq_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cq_smem;
@@ -123,7 +124,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
 #pragma unroll
   for (int t = 0; t < C::NCT; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b4ct[t][q] = p.bias[t * C::TN + (POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q)];
+    for (int q = 0; q < 4; ++q) b4ct[t][q] = DGRAD ? 0.f : p.bias[t * C::TN + (POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q)];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- prologue (once) ----
@@ -292,16 +293,25 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
       // 2 wm + (fk >> 1), column i; dz = fk & 1; register e: dy = e >> 1, dx = e & 1 ----
       const Slot sl = slot_of(bt, 2 * wm + (fk >> 1));
       if (sl.valid) {
-        bf16_t* ow = p.out + (long long)sl.n * C::OUT_IMG + (2 * sl.zp + (fk & 1) + 1) * C::OUT_PLANE + (2 * sl.yp + 1) * C::OUT_ROW + C::NOUT +
-                     ct * C::TN + wn * 64 + frow * 4;
+        const long long ow = (long long)sl.n * C::OUT_IMG + (2 * sl.zp + (fk & 1) + 1) * C::OUT_PLANE + (2 * sl.yp + 1) * C::OUT_ROW + C::NOUT + ct * C::TN +
+                             wn * 64 + frow * 4;
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
+            const long long oe = ow + (e >> 1) * C::OUT_ROW + (2 * i + (e & 1)) * C::NOUT;
             uint2 o;
-            o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b4[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b4[1], 0.f)) << 16);
-            o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b4[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b4[3], 0.f)) << 16);
-            *(uint2*)(ow + (e >> 1) * C::OUT_ROW + (2 * i + (e & 1)) * C::NOUT) = o;
+            if constexpr (DGRAD) {
+              const uint2 m = *(const uint2*)(p.mask + oe);
+              const float v0 = bf2f((bf16_t)(m.x & 0xffffu)) > 0.f ? acc[i][0][e] : 0.f, v1 = bf2f((bf16_t)(m.x >> 16)) > 0.f ? acc[i][1][e] : 0.f;
+              const float v2 = bf2f((bf16_t)(m.y & 0xffffu)) > 0.f ? acc[i][2][e] : 0.f, v3 = bf2f((bf16_t)(m.y >> 16)) > 0.f ? acc[i][3][e] : 0.f;
+              o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+              o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+            } else {
+              o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b4[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b4[1], 0.f)) << 16);
+              o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b4[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b4[3], 0.f)) << 16);
+            }
+            *(uint2*)(p.out + oe) = o;
           }
       }
     }

@@ -203,6 +203,8 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
           (const int*)(ws + c->unpad_off[i - 1]), c->act_stride[i], (T*)(ws + lo.dypre_off), (const int*)(ws + lo.win_tab_off),
           (const int*)(ws + lo.q_off_off), lo.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, rows, grads + lo.grad_b);
       RGP_HIP(hipGetLastError());
+    } else if (sizeof(T) == 2 && (i == 3 || i == 5) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+      RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));        // conv_patch.hip.h / conv_patch14.hip.h
     } else {
       EpiParams e = make_epi(b.dg, ws + lo.dypre_off, ws);
       e.mask = ws + c->act_off[i];

@@ -52,6 +52,7 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.bias = c->bias[layer];
   p.out = (bf16_t*)(c->ws + c->act_off[layer + 1]);
   p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
+  p.mask = nullptr;
   p.n_windows = n;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
@@ -71,6 +72,7 @@ static int run_conv_patch14(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.bias = c->bias[layer];
   p.out = (bf16_t*)(c->ws + c->act_off[layer + 1]);
   p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
+  p.mask = nullptr;
   p.n_windows = n;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
@@ -88,4 +90,34 @@ int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   if (layer == 2) return run_conv_patch<128, 256, 28, 8, false, false>(c, layer, n, s);
   if (layer == 3) return c->save ? run_conv_patch<256, 256, 28, 8, true, true>(c, layer, n, s) : run_conv_patch<256, 256, 28, 8, true, false>(c, layer, n, s);
   return set_err(RGP_EINVAL, "conv_patch: no kernel for layer %d", layer);
+}
+
+// input gradient of conv3b / conv4b (bf16): the un-pooled patch kernels on dY with the backward plan's rotated filter,
+// masked by the forward activation, written as dY of conv3a / conv4a
+int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  ConvPatchParams p;
+  p.in = (const bf16_t*)(c->ws + c->B[layer].dypre_off);
+  p.wp = (const bf16_t*)(c->ws + c->B[layer].dg.w_off);
+  p.bias = nullptr;
+  p.out = (bf16_t*)(c->ws + c->B[layer - 1].dypre_off);
+  p.argmax = nullptr;
+  p.mask = (const bf16_t*)(c->ws + c->act_off[layer]);
+  p.n_windows = n;
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  if (layer == 3) {
+    auto kern = conv_patch_bf16_kernel<256, 256, 28, 8, false, false, true>;
+    constexpr int smem = PatchCfg<256, 256, 28, 8, false>::SMEM;
+    RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+    kern<<<n_cu, 512, smem, s>>>(p);
+  } else if (layer == 5) {
+    auto kern = conv_patch14_bf16_kernel<512, false, false, true>;
+    constexpr int smem = Patch14Cfg<512, false>::SMEM;
+    RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+    kern<<<n_cu, 512, smem, s>>>(p);
+  } else {
+    return set_err(RGP_EINVAL, "conv_patch dgrad: no kernel for layer %d", layer);
+  }
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
 }
