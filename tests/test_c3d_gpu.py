@@ -156,3 +156,28 @@ def test_full_size_launch_chain_is_clip_independent(gpu, c3d_case):
     assert rel_err(f[:2].cpu().numpy(), ref_feat) < TOL['bf16']
     # the last replica too (another XCD's share of the tile list)
     assert rel_err(f[766:768].cpu().numpy(), f8[6:8].cpu().numpy()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 3, 5])
+def test_odd_window_counts_are_window_independent(gpu, c3d_case, n):
+    """The 14 x 14 patch kernels (conv4a / conv4b) tile PAIRS of pooled-row pairs, 7 per window: with an odd number of
+    windows the last block tile is half empty and block tiles straddle two windows.  The features of an n-window run
+    must be, bit for bit, the first n of an 8-window run (windows are independent; both reduce K in the same order),
+    and nothing may be written past the n-th window (the 8-window engine's buffers are separate, so a stray store
+    would show as a difference in a second run of the small engine after a large one)."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, v2, _, _ = c3d_case
+    v8 = torch.tensor(np.concatenate([v2, syn.video_windows(23, 6)]), device=gpu)
+    big = C3DEngine(8, dtype='bf16', device=gpu)
+    big.set_weights(p)
+    f8 = big.forward(v8)[0].clone()
+    small = C3DEngine(n, dtype='bf16', device=gpu)
+    small.set_weights(p)
+    fn = small.forward(v8[:n].contiguous())[0].clone()
+    assert torch.isfinite(fn).all()
+    assert torch.equal(fn, f8[:n])
+    # a larger engine run with fewer windows than its capacity: rows beyond n stay untouched by the tail tiles
+    f8b = big.forward(v8[:n].contiguous())[0]
+    assert torch.equal(f8b[:n], f8[:n])
