@@ -171,12 +171,6 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
         carry[o][r] = dh[o][r] * uu[o][r];
         dcp[o][r] = dc * (1.f - cc[o][r] * cc[o][r]);
         dzp[o][r] = du * uu[o][r] * (1.f - uu[o][r]);
-        if (ovalid[o][r]) {
-          const int c = orow[o][r] / 49, r49 = orow[o][r] - c * 49;
-          float* row = p.dxpre + (((long long)(clip0 + c) * T_ + t) * 49 + r49) * (3 * S) + ch;
-          row[0] = dzp[o][r];
-          row[2 * S] = dcp[o][r];
-        }
       }
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -184,6 +178,18 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
     arrive_wait(2 * (T_ - 1 - t));
     load_image(p.xch_c, img_a);
     __syncthreads();
+    // the plain outputs go out BEHIND the hand-off, under the MFMAs that follow (convgru_seq.hip.h): in front of it the
+    // hand-off's drain waits for their HBM acknowledgements
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ovalid[o][r]) {
+          const int c = orow[o][r] / 49, r49 = orow[o][r] - c * 49;
+          float* row = p.dxpre + (((long long)(clip0 + c) * T_ + t) * 49 + r49) * (3 * S) + ch;
+          row[0] = dzp[o][r];
+          row[2 * S] = dcp[o][r];
+        }
 
     // ---- d(r.h) = conv3x3(dc_pre; U^T): this wave's K quarter, reduced through LDS
     {
@@ -213,14 +219,20 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
       for (int r = 0; r < 4; ++r) {
         drp[o][r] = d[r] * hp[o][r] * rr[o][r] * (1.f - rr[o][r]);
         carry[o][r] += d[r] * rr[o][r];
-        if (ovalid[o][r]) {
-          const int c = orow[o][r] / 49, r49 = orow[o][r] - c * 49;
-          p.dxpre[(((long long)(clip0 + c) * T_ + t) * 49 + r49) * (3 * S) + S + ch] = drp[o][r];
-        }
       }
     }
+    auto store_drp = [&]() {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ovalid[o][r]) {
+            const int c = orow[o][r] / 49, r49 = orow[o][r] - c * 49;
+            p.dxpre[(((long long)(clip0 + c) * T_ + t) * 49 + r49) * (3 * S) + S + ch] = drp[o][r];
+          }
+    };
     // (the last step's carry is not needed by anybody: the recurrence starts from h_0 = 0, gaze_grcn.py:262)
-    if (t == 0) break;
+    if (t == 0) { store_drp(); break; }
 #pragma unroll
     for (int o = 0; o < 2; ++o)
       if (kq + 4 * o < NF) { publish_tile(p.xch_z, kq + 4 * o, dzp[o]); publish_tile(p.xch_r, kq + 4 * o, drp[o]); }
@@ -228,6 +240,7 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
     load_image(p.xch_z, img_a);
     load_image(p.xch_r, img_b);
     __syncthreads();
+    store_drp();                                           // behind the hand-off, as above
 
     // ---- carry += conv3x3([dz_pre | dr_pre]; [U_z ; U_r]^T)
     {

@@ -175,9 +175,10 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(cnt + ph, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // part 2: all 8 members have published; load the exchange image into an LDS image.  (Issuing the step's plain output
-  // stores between the two parts was measured: +25 % per step -- they queue in front of the poll and the image loads
-  // in this CU's memory pipeline; they go BEFORE the publish, overlapped with the gate math.)
+  // part 2: all 8 members have published; load the exchange image into an LDS image.  (The step's plain output stores
+  // are issued after it, see the loop.  Measured and not kept: Guideline 16's R2 form -- 8-byte {tag, 2 x bf16} granules
+  // polled by every member instead of image + counter: 0.61 ms instead of 0.23 at B = 64, T = 16; 25 atomic loads per
+  // thread and sweep over a 50 KB image are far beyond the <= 4 KB that form is meant for.)
   auto wait_load = [&](int ph, const bf16_t* xch, char* img) {
     if (tid == 0) {
       // bounded: ~1 s; a workgroup that timed out once stops waiting altogether (its results are poisoned below), so a
@@ -260,6 +261,14 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
     }
 #pragma unroll
     for (int o = 0; o < 2; ++o)
+      if (kq + 4 * o < NF) publish_tile(p.xch_rh, kq + 4 * o, rh[o]);
+    arrive(2 * t);
+    wait_load(2 * t, p.xch_rh, img_rh);
+    // this phase's plain outputs go out BEHIND the hand-off, under the candidate phase's MFMAs: in front of it they sit
+    // in the queue that arrive() drains (the hand-off then waits for their HBM acknowledgements), between its two parts
+    // they delay the poll and the image loads (+25 % per step, measured)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (ovalid[o][r]) {
@@ -267,11 +276,6 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
           p.uall[off] = u[o][r];
           if (p.rall) p.rall[off] = rgs[o][r];
         }
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-      if (kq + 4 * o < NF) publish_tile(p.xch_rh, kq + 4 * o, rh[o]);
-    arrive(2 * t);
-    wait_load(2 * t, p.xch_rh, img_rh);
 
     // ---- candidate phase on r.h, blend, batch-norm
     {
@@ -309,6 +313,14 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
         h_prev[o][r] = hn[o][r];
       }
     }
+    if (t + 1 < T_) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+        if (kq + 4 * o < NF) publish_tile(p.xch_h, kq + 4 * o, hn[o]);
+      arrive(2 * t + 1);
+      wait_load(2 * t + 1, p.xch_h, img_h);
+    }
+    // (outputs behind the hand-off, as above: they drain under the next step's z | r MFMAs)
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -321,13 +333,6 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
           const long long fr = (long long)(clip0 + c) * T_ + t;
           p.hbn[(fr * 81 + (r49 / 7 + 1) * 9 + (r49 % 7 + 1)) * S + ch] = f2bf(gam * (hn[o][r] * p.bn_inv_std) + bet);
         }
-    if (t + 1 < T_) {
-#pragma unroll
-      for (int o = 0; o < 2; ++o)
-        if (kq + 4 * o < NF) publish_tile(p.xch_h, kq + 4 * o, hn[o]);
-      arrive(2 * t + 1);
-    }
-    if (t + 1 < T_) wait_load(2 * t + 1, p.xch_h, img_h);
   }
   // a group that timed out must not look like a result
   if (s_timeout) {
