@@ -190,6 +190,10 @@ int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for
     const int rc = c3d_bwd_plan(c, a);
     if (rc != RGP_OK) { delete c; return rc; }
   }
+  // the patch kernels (conv_patch.hip.h) fetch plane slabs in whole LDS-DMA instructions: up to 76 pixels (39 KB) past the
+  // last row a tile uses, i.e. past the end of an activation / gradient image for a window's last tile -- always inside
+  // the workspace: this tail covers the case of an image that is the arena's last buffer
+  a.take(64 * 1024);
   c->ws_bytes = a.off;
   *plan = c;
   return RGP_OK;
