@@ -17,10 +17,22 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
   if (p.M <= 0 || p.nk <= 0 || p.N <= 0) return set_err(RGP_EINVAL, "wgrad: empty problem");
   const int n_kt = (p.nk + 3) / 4, n_nt = (p.N + BN - 1) / BN;
   const long long total_steps = (p.M + 31) / 32;
-  // row ranges (splits): enough for ~1000 blocks (RGP_WGK_BLOCKS overrides), at least 8
+  // row ranges (splits): enough for ~1000 blocks (RGP_WGK_BLOCKS overrides), at least 8 -- several rounds of blocks even
+  // out the tiles' different lengths.  Every block ends with one fp32 atomic per element of its 256 x BN tile, so a
+  // problem whose blocks would then run fewer than 256 steps (the head's and the recurrent cells' filter gradients:
+  // M = B T 49 rows) gets ONE round of blocks instead (2 per CU for the 128-wide tile, 1 for the 256-wide one): its
+  // atomic traffic, not its MFMAs, is what takes the time (cfg-4 training step 2.79 -> 2.38 ms, B 64 x T 16 4.23 -> 3.81).
   const int target = dev_knob("RGP_WGK_BLOCKS", 1024);
-  long long splits = std::max<long long>(8, target / (n_kt * n_nt));
+  const int tiles = n_kt * n_nt;
+  long long splits = std::max<long long>(8, target / tiles);
   splits = std::min(splits, total_steps);
+  if (total_steps / splits < 256) {
+    int n_cu = 256;
+    RGP_TRY(device_cu_count(&n_cu));
+    const int slots = (WNT == 4 && sizeof(T) == 2 ? 2 : 1) * n_cu;
+    splits = std::max<long long>(1, std::min<long long>(slots / tiles, total_steps / 16));
+    splits = std::max<long long>(1, std::min(splits, total_steps));
+  }
   WgradParams q = p;
   {
     const WgradGeom g = {p.D, p.H, p.W, p.x_sz, p.x_sy, p.x_sx, p.y_sz, p.y_sy, p.y_sx, p.y_org, (int)sizeof(T), p.x_img_stride, p.y_img_stride};
