@@ -58,8 +58,10 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static constexpr int PLANE_PIX = PPW * 128;             // pixels fetched per slab: 384 / 256 (348 / 180 used)
   static constexpr int PLANE_BYTES = PLANE_PIX * 64, PLANE_STRIDE = PLANE_BYTES + 256;
   static constexpr int BRING_OFF = (3 * PLANE_STRIDE + 32 + PLANE_BYTES + 1023) / 1024 * 1024;
-  static constexpr int BPW = NOUT / 128;                  // filter-slab DMA instructions per wave and step: 1 / 2
-  static constexpr int BSLOT = NOUT * 64;                 // 8 / 16 KB: NOUT filter rows x 32 K elements
+  static constexpr int NI = NOUT / (16 * WNW);            // 16-column MFMA tiles per wave: 4 (2 for the 64 / 128-channel
+                                                          // input gradients of conv2a / conv3a: wave tile 112 x 32)
+  static constexpr int BPW = (NOUT + 127) / 128;          // filter-slab DMA instructions per wave and step: 1 / 2
+  static constexpr int BSLOT = BPW * 128 * 64;            // 8 / 16 KB: filter rows (padded to 128: the packing pads too) x 32 K elements
   static constexpr int NSLOT = 4, AHEAD = 3;
   static constexpr int STG_OFF = BRING_OFF + NSLOT * BSLOT;
   // staged pooled tile (bias + ReLU applied, bf16) [WIN][NOUT + 8] and its arg-max codes [WIN][NOUT + 8] bytes: an area of
@@ -75,10 +77,11 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static constexpr int OW = POOL ? HW / 2 : HW, OD = POOL ? DEPTH / 2 : DEPTH;   // output extent
   static constexpr int OUT_ROW = (OW + 2) * NOUT, OUT_PLANE = (OW + 2) * OUT_ROW, OUT_IMG = (OD + 2) * OUT_PLANE;
   static constexpr int CGN = NOUT / 8;                    // epilogue: 8-channel groups
-  static_assert(WNW * 64 == NOUT && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0, "tile shape");
+  static_assert(WNW * 16 * NI == NOUT && (NI == 4 || (NI == 2 && !POOL)) && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0,
+                "tile shape");
   static_assert((WP * 64) % 256 == 128, "row pitch = 128 (mod 256): the bank argument of the header");
   static_assert(SMEM <= 160 * 1024, "LDS budget");
-  static_assert(WIN * CGN == 2 * 448, "epilogue: two items per thread (448 of the 512 threads)");
+  static_assert(!POOL || WIN * CGN == 2 * 448, "pooled epilogue: two items per thread (448 of the 512 threads)");
   static_assert((STG_LD * 2) % 16 == 0 && STG_LD % 8 == 0, "staging rows keep 16- / 8-byte alignment");
 };
 
@@ -95,11 +98,15 @@ static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
 // stores 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
 // DGRAD (!POOL): the same convolution as the input gradient of a layer (in = dY before pooling, halo-padded; filter =
 // the rotated, in/out-swapped one of the backward plan): no bias, no ReLU, the result masked by the forward activation.
-template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX = false, bool DGRAD = false>
+// DENSE (DGRAD only): the output is the dense, un-masked [n][D*HW*HW][NOUT] image the un-pool kernel consumes (gradient
+// w.r.t. a pooled layer's output).
+template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX = false, bool DGRAD = false, bool DENSE = false>
 static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvPatchParams p) {
+  static_assert(!DENSE || DGRAD, "dense output: input gradients only");
   static_assert(POOL || !ARGMAX, "arg-max codes belong to the pooled layers");
   static_assert(!POOL || !DGRAD, "the input gradient is an un-pooled convolution");
   using C = PatchCfg<CIN, NOUT, HW, DEPTH, POOL>;
+  constexpr int NI = C::NI;
   extern __shared__ __attribute__((aligned(16))) char cp_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cp_smem;
   const int tid = threadIdx.x;
@@ -140,8 +147,9 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   // igemm_wide.hip.h (physical chunk c of row r holds logical chunk c ^ ((-(r >> 2)) & 3))
   const int brow = lane >> 2;
   const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
-  // filter row (output channel) behind row brow of 1-KB block blk: blk * 16 + brow, or (!POOL) 64 (blk >> 2) + 4 brow + (blk & 3)
-  auto b_row = [&](int blk) { return POOL ? blk * 16 + brow : (blk >> 2) * 64 + brow * 4 + (blk & 3); };
+  // filter row (output channel) behind row brow of 1-KB block blk: blk * 16 + brow, or (!POOL) wave blk / NI, column
+  // tile blk % NI: channel 16 NI (blk / NI) + NI brow + blk % NI (rows >= NOUT of a 64-channel filter are the packing's zeros)
+  auto b_row = [&](int blk) { return POOL ? blk * 16 + brow : (blk / NI) * (16 * NI) + brow * NI + (blk % NI); };
   const char* b_src[C::BPW];
 #pragma unroll
   for (int u = 0; u < C::BPW; ++u) b_src[u] = (const char*)(p.wp + (long long)b_row(wave * C::BPW + u) * C::K) + bchk * 16;
@@ -164,12 +172,12 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     const int ypl = w0 / C::XPN, xp = w0 - ypl * C::XPN + r_ws;
     rowaddr[i] = lds0 + ((2 * ypl + r_dy) * C::WP + 2 * xp + r_dx) * 64 + fk * 16;
   }
-  const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
+  const unsigned b_addr = lds0 + C::BRING_OFF + (wn * NI) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
 
   const int cg = tid % C::CGN;                                // POOL epilogue, store pass: this thread's 8 output channels
-  float b4[4];                                                // bias of this lane's 4 MFMA columns
+  float b4[NI];                                               // bias of this lane's NI MFMA columns
 #pragma unroll
-  for (int q = 0; q < 4; ++q) b4[q] = DGRAD ? 0.f : p.bias[POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q];
+  for (int q = 0; q < NI; ++q) b4[q] = DGRAD ? 0.f : p.bias[POOL ? wn * 64 + q * 16 + frow : wn * (16 * NI) + frow * NI + q];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -191,11 +199,11 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     const bool has_next = t_next < nt;
     const int tile_next = has_next ? tile_of(t_next) : tile;
 
-    f32x4 acc[7][4];
+    f32x4 acc[7][NI];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (group_b) __builtin_amdgcn_s_barrier();               // run one half-step behind group A
 
     // one group of 9 taps (ky, kx) of plane offset kz, K steps s0 .. s0 + 8 of the tile; NPL plane fetches (PPW
@@ -211,7 +219,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
       for (int t9 = 0; t9 < 9; ++t9) {
         // ---------------- LOAD ----------------
         const int s = s0 + t9;
-        f32x4 af[7], bf[4];
+        f32x4 af[7], bf[NI];
         const unsigned bb = b_addr + slot * C::BSLOT;
         auto reads = [&](auto T9) {
           constexpr int t = decltype(T9)::value;
@@ -232,8 +240,10 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
         }
         bf[0] = cp_lds_read128<0>(bb);
         bf[1] = cp_lds_read128<1024>(bb);
-        bf[2] = cp_lds_read128<2048>(bb);
-        bf[3] = cp_lds_read128<3072>(bb);
+        if constexpr (NI == 4) {
+          bf[2] = cp_lds_read128<2048>(bb);
+          bf[3] = cp_lds_read128<3072>(bb);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (t9 == 0) {
           if (NPL >= 1) dma_plane(pl_a, ka);
@@ -255,7 +265,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #pragma unroll
         for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bf[j]));
+        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bf[j]));
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -264,7 +274,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
+          for (int j = 0; j < NI; ++j) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -333,27 +343,38 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     } else {
       // ---- epilogue: bias + ReLU, 8-byte stores from registers.  Register e of accumulator (i, j): row 4 fk + e of
       // m-tile i = window 2 (7 wm + i) + (fk >> 1), dz = fk & 1, dy = e >> 1, dx = e & 1; channel 64 wn + 4 frow + j ----
-      const long long obase = (long long)tn * C::OUT_IMG + (2 * zp + 1 + (fk & 1)) * C::OUT_PLANE + (4 * yp + 1) * C::OUT_ROW + NOUT + wn * 64 + frow * 4;
+      // position of (window w, dz, dy, dx): halo-padded image, or (DENSE) natural (z, y, x) order without halo
+      constexpr int ROWS = DENSE ? HW * NOUT : C::OUT_ROW, PLANES = DENSE ? HW * ROWS : C::OUT_PLANE;
+      constexpr long long IMG = DENSE ? (long long)DEPTH * PLANES : (long long)C::OUT_IMG;
+      constexpr int H1 = DENSE ? 0 : 1;
+      const long long obase = (long long)tn * IMG + (2 * zp + H1 + (fk & 1)) * PLANES + (4 * yp + H1) * ROWS + H1 * NOUT + wn * (16 * NI) + frow * NI;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int w = 2 * (7 * wm + i) + (fk >> 1);
         const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
-        const long long ow = obase + (2 * ypl) * C::OUT_ROW + (2 * xp) * NOUT;
+        const long long ow = obase + (2 * ypl) * ROWS + (2 * xp) * NOUT;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const long long oe = ow + (e >> 1) * C::OUT_ROW + (e & 1) * NOUT;
-          uint2 o;
-          if constexpr (DGRAD) {
-            const uint2 m = *(const uint2*)(p.mask + oe);
-            const float v0 = bf2f((bf16_t)(m.x & 0xffffu)) > 0.f ? acc[i][0][e] : 0.f, v1 = bf2f((bf16_t)(m.x >> 16)) > 0.f ? acc[i][1][e] : 0.f;
-            const float v2 = bf2f((bf16_t)(m.y & 0xffffu)) > 0.f ? acc[i][2][e] : 0.f, v3 = bf2f((bf16_t)(m.y >> 16)) > 0.f ? acc[i][3][e] : 0.f;
-            o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-            o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
-          } else {
-            o.x = (unsigned)f2bf(fmaxf(acc[i][0][e] + b4[0], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][1][e] + b4[1], 0.f)) << 16);
-            o.y = (unsigned)f2bf(fmaxf(acc[i][2][e] + b4[2], 0.f)) | ((unsigned)f2bf(fmaxf(acc[i][3][e] + b4[3], 0.f)) << 16);
+          const long long oe = ow + (e >> 1) * ROWS + (e & 1) * NOUT;
+          float v[NI];
+#pragma unroll
+          for (int j = 0; j < NI; ++j) v[j] = DGRAD ? acc[i][j][e] : fmaxf(acc[i][j][e] + b4[j], 0.f);
+          if constexpr (DGRAD && !DENSE) {
+            unsigned m[NI / 2];
+            if constexpr (NI == 4) { const uint2 mm = *(const uint2*)(p.mask + oe); m[0] = mm.x; m[1] = mm.y; }
+            else m[0] = *(const unsigned*)(p.mask + oe);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              if (!(bf2f((bf16_t)((m[j >> 1] >> (16 * (j & 1))) & 0xffffu)) > 0.f)) v[j] = 0.f;
           }
-          *(uint2*)(p.out + oe) = o;
+          if constexpr (NI == 4) {
+            uint2 o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *(uint2*)(p.out + oe) = o;
+          } else {
+            *(unsigned*)(p.out + oe) = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          }
         }
       }
     }

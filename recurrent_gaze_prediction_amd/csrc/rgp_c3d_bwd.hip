@@ -191,8 +191,12 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     const C3dBwdLayer& lo = c->B[i - 1];
     IgemmParams p = make_params(b.dg, ws + b.dypre_off, ws, n);
     if (pooled(i - 1)) {
-      EpiParams e = make_epi(b.dg, ws + c->dyp_off, ws);
-      RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+      if (sizeof(T) == 2 && (i == 1 || i == 2) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+        RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));      // conv_patch.hip.h, dense output
+      } else {
+        EpiParams e = make_epi(b.dg, ws + c->dyp_off, ws);
+        RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+      }
       const C3dLayerSpec& ll = kLayers[i - 1];
       const int PR = (ll.D / ll.pd) * (ll.H / ll.ph) * (ll.H / ll.ph);
       const long long rows = (long long)n * PR;

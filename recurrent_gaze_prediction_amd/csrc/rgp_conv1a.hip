@@ -92,8 +92,8 @@ int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   return set_err(RGP_EINVAL, "conv_patch: no kernel for layer %d", layer);
 }
 
-// input gradient of conv3b / conv4b (bf16): the un-pooled patch kernels on dY with the backward plan's rotated filter,
-// masked by the forward activation, written as dY of conv3a / conv4a
+// input gradients (bf16): the un-pooled patch kernels on dY with the backward plan's rotated filter.  conv3b / conv4b:
+// masked by the forward activation, written as dY of conv3a / conv4a; conv2a / conv3a: dense, for the un-pool kernel
 int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   ConvPatchParams p;
   p.in = (const bf16_t*)(c->ws + c->B[layer].dypre_off);
@@ -105,7 +105,22 @@ int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.n_windows = n;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
-  if (layer == 3) {
+  if (layer == 1 || layer == 2) {
+    // into a pooled layer: dense, un-masked [n][D*H*W][cin] image for the un-pool kernel (wave tiles of 112 x 32)
+    p.out = (bf16_t*)(c->ws + c->dyp_off);
+    p.mask = nullptr;
+    if (layer == 1) {
+      auto kern = conv_patch_bf16_kernel<128, 64, 56, 16, false, false, true, true>;
+      constexpr int smem = PatchCfg<128, 64, 56, 16, false>::SMEM;
+      RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+      kern<<<n_cu, 512, smem, s>>>(p);
+    } else {
+      auto kern = conv_patch_bf16_kernel<256, 128, 28, 8, false, false, true, true>;
+      constexpr int smem = PatchCfg<256, 128, 28, 8, false>::SMEM;
+      RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+      kern<<<n_cu, 512, smem, s>>>(p);
+    }
+  } else if (layer == 3) {
     auto kern = conv_patch_bf16_kernel<256, 256, 28, 8, false, false, true>;
     constexpr int smem = PatchCfg<256, 256, 28, 8, false>::SMEM;
     RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
