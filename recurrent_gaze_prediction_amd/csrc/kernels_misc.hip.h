@@ -53,6 +53,37 @@ __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restric
   }
 }
 
+// The same packing for sources whose OUTPUT-channel index is the contiguous one (s_n == 1: HWIO / DHWIO forward filters,
+// re-packed after every optimizer step): a 32 x 32 (n, c) tile of one tap goes through LDS so that both the fp32 reads
+// (along n) and the packed writes (along c) are coalesced.  The kernel above reads such a source with a stride of
+// cout floats per lane.  grid = (ceil(cin_k / 32), ceil(n_rows / 32), ntaps), 256 threads as 32 x 8.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_filter_tiled_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                                const int* __restrict__ tap_src, int ntaps, int cin_k, int cin_src,
+                                                                int n_rows, int row0, int K, long long s_tap, long long s_c, int k0,
+                                                                int row_step, int chunk_major) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tap = blockIdx.z;
+  const int ts = tap_src ? tap_src[tap] : tap;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, n = n0 + tx;
+    float v = 0.f;
+    if (ts >= 0 && c < cin_src && n < n_rows) v = src[ts * s_tap + n + c * s_c];
+    tile[ty + 8 * k][tx] = v;
+  }
+  __syncthreads();
+  const int c = c0 + tx;
+  if (c >= cin_k) return;
+  const int col = chunk_major ? (c / chunk_major) * (ntaps * chunk_major) + tap * chunk_major + (c % chunk_major) : tap * cin_k + k0 + c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = n0 + ty + 8 * k;
+    if (n < n_rows) dst[(long long)(row0 + n * row_step) * K + col] = Elem<T>::to(tile[tx][ty + 8 * k]);
+  }
+}
+
 // Exact algebraic fold of the 7x7 transposed conv (12 channels) with the 12->1
 // projection (gaze_grcn.py:353-361): G[tap][c] = sum_o F[tap][o][c] * out_W[o].
 static __global__ void fold_head_filter_kernel(const float* __restrict__ f, const float* __restrict__ out_w,

@@ -161,6 +161,13 @@ int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int r
                 int grouped = 0, int row_step = 1) {
   // grouped != 0: the packed K axis holds several source filters side by side per tap (column
   // offset k0, cin_src channels each); the buffer is pre-zeroed, padding is never written.
+  if (!grouped && d.s_n == 1 && d.cin_k >= 32 && n_rows >= 32) {      // output channel contiguous in the source: tiled transpose
+    const dim3 grid((d.cin_k + 31) / 32, (n_rows + 31) / 32, d.pack_taps);
+    pack_filter_tiled_kernel<T><<<grid, 256, 0, s>>>(src, (T*)(ws + d.w_off), (const int*)(ws + d.tap_src_off), d.pack_taps, d.cin_k,
+                                                     d.cin_src, n_rows, row0, d.K, d.s_tap, d.s_c, k0, row_step, d.chunk_major);
+    RGP_HIP(hipGetLastError());
+    return RGP_OK;
+  }
   const long long total = (long long)n_rows * d.pack_taps * d.cin_k;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
   pack_filter_kernel<T><<<blocks, 256, 0, s>>>(src, (T*)(ws + d.w_off), (const int*)(ws + d.tap_src_off), d.pack_taps,
