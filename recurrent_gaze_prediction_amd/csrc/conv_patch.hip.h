@@ -1,7 +1,12 @@
-// C3D conv2a (3x3x3, 64->128) and conv3b (256->256), pad 1, + bias + ReLU + 2x2x2 max-pool for gfx950, bf16, inference.
-// Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:67-107 (conv2a, pool2), 133-173 (conv3b, pool3).
-// The text below describes conv2a; conv3b is the same kernel at 28 x 28 x 8 positions, 8 channel sweeps of 32, tiles of
-// 2 x 14 pooling windows x 256 channels (waves 2 (M) x 4 (N)), plane slabs of 6 x 30 pixels and 16 KB filter slabs.
+// The large 3x3x3 convolutions of the C3D stack on 56 x 56 and 28 x 28 planes for gfx950, bf16 -- conv2a (64->128) + pool2,
+// conv3a (128->256), conv3b (256->256) + pool3, forward (inference and training: arg-max codes of the pooling), and
+// their input gradients (conv3b's masked by the forward activation; conv2a's / conv3a's dense, for the un-pool kernel).
+// Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:67-107 (conv2a, pool2), 108-173 (conv3a, conv3b,
+// pool3); the gradients are tf.gradients through them (base.py:278-281).  conv4a / conv4b: conv_patch14.hip.h.
+// The text below describes conv2a's forward; the other instances are the same kernel at 28 x 28 x 8 positions with
+// 4 / 8 channel sweeps of 32, tiles of 2 x 14 pooling windows x 256 channels (waves 2 (M) x 4 (N)), plane slabs of
+// 6 x 30 pixels and 16 KB filter slabs; the two dense input gradients have 64 / 128 output channels and use wave tiles
+// of 112 x 32 (NI = 2) on the same block tiles.
 //
 // Why a kernel of its own: conv2a is the largest layer of the stack (22.7 of 78.8 TFLOP per 1024 windows) and the one
 // the general implicit-GEMM tile serves worst.  With N = 128 only the A tile can grow, and the A operand -- one
