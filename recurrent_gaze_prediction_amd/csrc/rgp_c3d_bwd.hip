@@ -15,6 +15,7 @@
 #include "rgp_c3d_plan.h"
 #include "wgrad_launch.h"
 #include "conv1a_wgrad.hip.h"
+#include "wgrad_patch.hip.h"
 
 using namespace rgp;
 
@@ -116,6 +117,31 @@ __global__ void conv1a_unpack_grad_kernel(const float* __restrict__ dw1, float* 
   grad[i] += dw1[(long long)(t2 * 16 + kx * 4 + c) * 64 + n];
 }
 
+// conv2a / conv3a / conv3b filter gradients (bf16): one block per (32 input channels, 64 output channels, column range)
+template <int CIN, int COUT, int HW, int DEPTH>
+int launch_wgrad_patch(const bf16_t* x, const bf16_t* dy, float* dw, int n, hipStream_t s) {
+  using Cfg = WgpCfg<CIN, COUT, HW, DEPTH>;
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  WgradPatchParams p;
+  p.x = x; p.dy = dy; p.dw = dw; p.n_windows = n;
+  p.splits = std::max(8, n_cu / (Cfg::CS * Cfg::NS) / 8 * 8);          // a multiple of 8: one XCD per column range
+  auto kern = wgrad_patch_bf16_kernel<CIN, COUT, HW, DEPTH>;
+  RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
+  kern<<<Cfg::CS * Cfg::NS * p.splits, 512, Cfg::SMEM, s>>>(p);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+int run_wgrad_patch(rgp_c3d* c, int layer, int n, float* dw, hipStream_t s) {
+  const bf16_t* x = (const bf16_t*)(c->ws + c->act_off[layer]);
+  const bf16_t* dy = (const bf16_t*)(c->ws + c->B[layer].dypre_off);
+  if (layer == 1) return launch_wgrad_patch<64, 128, 56, 16>(x, dy, dw, n, s);
+  if (layer == 2) return launch_wgrad_patch<128, 256, 28, 8>(x, dy, dw, n, s);
+  if (layer == 3) return launch_wgrad_patch<256, 256, 28, 8>(x, dy, dw, n, s);
+  return set_err(RGP_EINVAL, "wgrad_patch: no kernel for layer %d", layer);
+}
+
 template <typename T>
 int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, float* grads, hipStream_t s) {
   char* ws = c->ws;
@@ -179,6 +205,10 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         RGP_TRY((launch_wgrad<T, G0>(p, s)));
         conv1a_unpack_grad_kernel<<<(27 * 3 * 64 + 255) / 256, 256, 0, s>>>(p.dW, grads + b.grad_w);
         RGP_HIP(hipGetLastError());
+      } else if (sizeof(T) == 2 && i >= 1 && i <= 3 && ((dev_knob("RGP_WGPATCH", 1) >> (i - 1)) & 1)) {
+        // wgrad_patch.hip.h: conv2a (-0.9 ms per 256 windows against wgrad_kernel); conv3a / conv3b measured
+        // 0.2-0.3 ms SLOWER there than wgrad_kernel's 256-wide tile and stay on it (dev builds: mask bits 1, 2)
+        RGP_TRY(run_wgrad_patch(c, i, n, grads + b.grad_w, s));
       } else {
         p.dW = grads + b.grad_w;
         RGP_TRY((launch_wgrad<T, 1>(p, s)));

@@ -32,10 +32,11 @@ def spawn_ranks(n_ranks, script, argv):
     return subprocess.call(cmd, env=env)
 
 
-def init(backend=None, device=None):
-    """Initialise the default process group when WORLD_SIZE > 1; returns the module or None."""
+def init(backend=None, device=None, force=False):
+    """Initialise the default process group when WORLD_SIZE > 1; returns the module or None.  `force` builds the
+    group for a single rank too (tests/test_dist_gpu.py: the RCCL path on a one-GPU box)."""
     rank, _, world = env_world()
-    if world <= 1:
+    if world <= 1 and not force:
         return None
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -1,0 +1,26 @@
+"""GPU: the RCCL leg of dist.py on hardware, as far as one GPU allows (a one-rank `nccl` process group in a child
+process; see tests/rccl_world1_child.py).  The N > 1 arithmetic is covered on CPU by tests/test_dist_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_one_rank_group_runs_the_reducer(gpu):
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rccl_world1_child.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['backend'] == 'nccl' and out['world'] == 1
+    assert out['max'] == 1.25 and out['sum'] == 2.5 and out['avg_identity']
+    assert out['loss'][0] == out['loss'][1], out                 # forward: deterministic
+    assert out['grad_rms_rel'] < 1e-5, out
+    assert abs(out['gnorm'][0] - out['gnorm'][1]) < 1e-4 * abs(out['gnorm'][0]), out
+    assert abs(out['loss_after_2_steps'][0] - out['loss_after_2_steps'][1]) < 1e-3 * abs(out['loss_after_2_steps'][0]), out
+    # the head's flat buffer + the eight conv layers' buckets went through RCCL every step
+    assert out['bytes_reduced_per_step'] > 100e6, out
