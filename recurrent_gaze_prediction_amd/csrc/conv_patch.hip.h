@@ -41,6 +41,10 @@
 
 #include "igemm.hip.h"
 
+#ifndef RGP_PLANE_AUX
+#define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured)
+#endif
+
 namespace rgp {
 
 struct ConvPatchParams {
@@ -145,7 +149,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     for (int u = 0; u < C::PPW; ++u) {
       const int j = wave * C::PPW + u;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 16 + dpix) * (CIN * 2) + dchk * 16),
-                                       (__attribute__((address_space(3))) void*)(cp_smem + plane_base(k) + j * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(cp_smem + plane_base(k) + j * 1024), 16, 0, RGP_PLANE_AUX);
     }
   };
   // filter slab of K step (cc, tap): this wave's BPW of its 1-KB blocks (16 filter rows x 64 B), chunk-swizzled like

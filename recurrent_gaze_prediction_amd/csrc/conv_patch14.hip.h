@@ -19,6 +19,10 @@
 
 #include "conv_patch.hip.h"
 
+#ifndef RGP_PLANE_AUX
+#define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured)
+#endif
+
 namespace rgp {
 
 template <int CIN, bool POOL> struct Patch14Cfg {
@@ -96,7 +100,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u * 16 + dpix) * (CIN * 2) + dchk * 16),
                                        (__attribute__((address_space(3))) void*)(cq_smem + plane_base(k) + ((wave >> 1) * 4 + 2 * (wave & 1) + u) * C::LROW),
-                                       16, 0, 0);
+                                       16, 0, RGP_PLANE_AUX);
   };
   // filter slab (conv_patch.hip.h), rows of column tile ct
   const int brow = lane >> 2;

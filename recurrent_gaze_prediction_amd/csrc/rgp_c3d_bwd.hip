@@ -205,9 +205,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         RGP_TRY((launch_wgrad<T, G0>(p, s)));
         conv1a_unpack_grad_kernel<<<(27 * 3 * 64 + 255) / 256, 256, 0, s>>>(p.dW, grads + b.grad_w);
         RGP_HIP(hipGetLastError());
-      } else if (sizeof(T) == 2 && i >= 1 && i <= 3 && ((dev_knob("RGP_WGPATCH", 1) >> (i - 1)) & 1)) {
-        // wgrad_patch.hip.h: conv2a (-0.9 ms per 256 windows against wgrad_kernel); conv3a / conv3b measured
-        // 0.2-0.3 ms SLOWER there than wgrad_kernel's 256-wide tile and stay on it (dev builds: mask bits 1, 2)
+      } else if (sizeof(T) == 2 && i >= 1 && i <= 3 && ((dev_knob("RGP_WGPATCH", 7) >> (i - 1)) & 1)) {
+        // wgrad_patch.hip.h: conv2a 5.2 -> 4.0 ms, conv3a 2.3 -> 2.3, conv3b 4.8 -> 4.3 ms per 256 windows against
+        // wgrad_kernel (dev builds: one mask bit per layer)
         RGP_TRY(run_wgrad_patch(c, i, n, grads + b.grad_w, s));
       } else {
         p.dW = grads + b.grad_w;

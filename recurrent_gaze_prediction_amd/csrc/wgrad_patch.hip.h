@@ -10,17 +10,29 @@
 //  * it walks columns (window, 4 image rows) through the planes z like conv1a.hip.h: a ring of input plane slabs
 //    (6 rows x (W+2) pixels x 64 B) and a double-buffered dY slab (4 rows x (W+2) pixels x 128 B) in LDS; per group of
 //    224 positions (one plane at 56 x 56, two at 28 x 28) one new slab of each is fetched while the group computes:
-//    2.2 KB of LDS-DMA per MFLOP.
+//    2.2 KB of LDS-DMA per MFLOP.  At 28 x 28 the ring has 8 slots, so the first four planes of the NEXT column are
+//    fetched under the last group of this one (no exposed prologue); at 56 x 56 LDS holds 4 slots and a column
+//    (16 groups) starts with an exposed fetch.
 //  * the 54 (tap, 16-channel tile) units are dealt to the 8 waves (7,7,7,7,7,7,6,6); a unit's accumulators are 4 tiles
 //    of 16 x 16 (64 output channels): 112 registers per wave, kept for the whole column range of the block and added
 //    to dW with fp32 atomics at the end (27 x 32 x 64 floats per block).
 //  * fragments: both operands have the reduction index (the position) on the strided axis, so they are read with
-//    ds_read_b64_tr_b16 (wgrad.hip.h): a lane supplies the address of ITS row, so the 8 positions of a k-group can be
-//    any pixels -- the per-lane addresses of the 14 (step, half) position groups are tabulated once; a tap is a
-//    wave-uniform offset.  The dY slab's 32-byte segments are XOR-swizzled per pixel on the DMA source side (8 rows of
-//    a read fall in 8 different bank groups); the X slab is not (a tap shifts the pixel, so the swizzle could not be
-//    an immediate): its reads are at most 2-way conflicted.
+//    ds_read_b64_tr_b16 (wgrad.hip.h): a lane supplies the address of ITS position.  The MFMA's k slot (step s, lane
+//    group g, half h, q) is mapped to image row g, column 8 s + 4 h + q (28 x 28: plane and column from 2 s + h): a
+//    lane's row and q never change, so every read address is  base register + IMMEDIATE  -- one base per unit for X
+//    (lane constant + the tap's wave-uniform offset + ring slot, recomputed per group: 2 VALU per unit), four for dY.
+//    No per-read address arithmetic (the first version spent 154 VALU per 196 MFMAs on it).
+//  * banks: a 32-lane half of a read touches 2 rows x 4 consecutive pixels x 32 B.  X (64-byte pixel slices, row pitch
+//    = 128 mod 256): the 32-byte half of a pixel is stored at ct ^ (slab row & 1); dY (128-byte pixels): its 32-byte
+//    segment seg at seg ^ (((x >> 1) & 1) | ((row & 1) << 1)).  Both swizzles are applied on the DMA's SOURCE side (a
+//    lane picks which 16 bytes it fetches) and are lane constants (XOR with the tap's row parity for X) on the read
+//    side: every read covers the 64 banks exactly once.
+//  * the step-0 fragments of the next group are requested right after the barrier that publishes its slabs, in front
+//    of the last step's MFMAs of the current group (the two fragment register sets alternate), so the LDS latency at
+//    a group boundary is covered.
 #pragma once
+#include <type_traits>
+
 #include "igemm.hip.h"
 
 namespace rgp {
@@ -41,35 +53,52 @@ template <int CIN, int COUT, int HW, int DEPTH> struct WgpCfg {
   static constexpr int COLS = HW / 4;                     // columns per window
   static constexpr int XI = (6 * WP + 15) / 16;           // LDS-DMA instructions per input plane slab (16 pixels x 64 B)
   static constexpr int XBUF = XI * 1024;
-  static constexpr int NXB = 2 * ZS + 2;                  // ring: ZS + 2 planes in use, ZS in flight
   static constexpr int DI = 4 * WP / 8;                   // instructions per dY plane slab (8 pixels x 128 B)
   static constexpr int DYPLANE = DI * 1024, DYBUF = ZS * DYPLANE;
+  // ring of input plane slabs: ZS + 2 planes in use, ZS (next group of the column) or ZS + 2 (first group of the
+  // next column) in flight
+  static constexpr bool SEAMLESS = (2 * ZS + 4) * XBUF + 2 * DYBUF <= 160 * 1024;
+  static constexpr int NXB = SEAMLESS ? 2 * ZS + 4 : 2 * ZS + 2;
   static constexpr int DY_OFF = NXB * XBUF;
   static constexpr int SMEM = DY_OFF + 2 * DYBUF;
-  static_assert(ZS * 4 * HW == 224 && (4 * WP) % 8 == 0 && DEPTH % ZS == 0 && CIN % 32 == 0 && COUT % 64 == 0, "group shape");
+  static_assert(ZS * 4 * HW == 224 && (4 * WP) % 8 == 0 && DEPTH % (2 * ZS) == 0 && CIN % 32 == 0 && COUT % 64 == 0, "group shape");
+  static_assert((WP * 64) % 256 == 128 && (WP * 128) % 256 == 0, "row pitches assumed by the bank swizzles");
   static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
 typedef int i32x2_wg __attribute__((ext_vector_type(2)));
 typedef int i32x4_wg __attribute__((ext_vector_type(4)));
 
+template <int OFF>
 static __device__ __forceinline__ i32x2_wg wgp_tr_read(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
   i32x2_wg v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
+
+// accumulate in place: the tied operand keeps each accumulator in ONE register quad for the whole kernel (left to the
+// register allocator, the results rotate through the fragment registers and the loop-carried state needs spills).
+// An accumulator is touched once per 28 MFMAs and read by nothing else inside the loop: no software wait states needed.
+static __device__ __forceinline__ void wgp_mfma(f32x4& acc, const i32x4_wg& a, const i32x4_wg& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+struct WgpFrags {                                             // fragments of one step: dY (4 output tiles) and X (7 units), two halves
+  i32x2_wg bl[4], bh[4], al[7], ah[7];
+};
 
 template <int CIN, int COUT, int HW, int DEPTH>
 static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const WgradPatchParams p) {
   using C = WgpCfg<CIN, COUT, HW, DEPTH>;
-  constexpr int WP = C::WP, ZS = C::ZS;
+  constexpr int WP = C::WP, ZS = C::ZS, NXB = C::NXB;
   extern __shared__ __attribute__((aligned(16))) char wp_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wp_smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fcol = lane & 15, g = lane >> 4, q = fcol >> 2, pp = fcol & 3;
-  if (lds0 & 127u) __builtin_trap();                          // the dY segment swizzle is an XOR on address bits 5-6
+  if (lds0 & 255u) __builtin_trap();                          // the swizzles are XORs on address bits 5-6 of 256-byte aligned rows
 
   // block -> (channel slice cs, output slice ns, column range).  Consecutive workgroup ids sit on different XCDs: the
   // CS x NS blocks of one column range are put on ONE XCD (id & 7), so that every input pixel and dY pixel -- of which
@@ -80,34 +109,25 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
   const int cs = combo % C::CS, ns = combo / C::CS;
   const int ncols = p.n_windows * C::COLS;
   const int cper = (ncols + p.splits - 1) / p.splits;
-  int col = split * cper;
-  const int col_end = min(col + cper, ncols);
-  if (col >= col_end) return;
+  const int col0 = split * cper;
+  const int col_end = min(col0 + cper, ncols);
+  if (col0 >= col_end) return;
+  const int n_groups = (col_end - col0) * C::NG;              // even (NG is)
 
-  // ---- per-lane position tables: (step s, half h) -> position m = 32 s + 8 g + 4 h + q of the group ----
-  unsigned xa[7][2], ya[7][2];
-  unsigned zlm = 0;                                           // bit 2 s + h: the position lies in the group's second plane
-#pragma unroll
-  for (int s = 0; s < 7; ++s)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int m = 32 * s + 8 * g + 4 * h + q;
-      const int zl = m / (4 * HW), rr = (m / HW) % 4, xx = m % HW;
-      xa[s][h] = (unsigned)((rr * WP + xx) * 64 + pp * 8);
-      const int pi = zl * (4 * WP) + rr * WP + xx + 1;        // pixel of the dY slab (its rows start at x = -1)
-      ya[s][h] = (unsigned)(pi * 128 + pp * 8 + ((((pi >> 1) & 1) | (((pi >> 3) & 1) << 1)) << 5));
-      if (zl) zlm |= 1u << (2 * s + h);
-    }
   // this wave's units: channel tile ct, taps (wave >> 1) + 4 i
   const int ct = wave & 1, tap0 = wave >> 1;
 
-  // ---- DMA: instruction t of a group's fetch list = X plane slabs (ZS x XI), then dY plane slabs (ZS x DI) ----
+  // ---- read-side lane constants.  k slot (s, g, h, q) of a step = image row g of the column, x = 8 s + 4 h + q
+  // (28 x 28: u = 2 s + h, plane u / 7, x = 4 (u % 7) + q) ----
+  const unsigned xl0 = (unsigned)((g * WP + q) * 64 + pp * 8 + 32 * ((ct ^ g) & 1));      // tap rows of even ky; odd ky: ^ 32
+  const unsigned swl = (unsigned)(((q >> 1) & 1) | ((g & 1) << 1));
+  unsigned yl[4];                                                                          // dY: output tile j -> segment j ^ swl
+#pragma unroll
+  for (int j = 0; j < 4; ++j) yl[j] = (unsigned)((g * WP + q + 1) * 128 + pp * 8) + (((unsigned)j ^ swl) << 5);
+
+  // ---- DMA: instruction t of a group's fetch list = X plane slabs (np x XI), then dY plane slabs (ZS x DI) ----
   const int xpix = lane >> 2, xchk = lane & 3;                // X: 16 pixels x 4 chunks of 16 B
-  // dY: 8 pixels x 8 chunks per instruction; the 32-byte segment seg of slab pixel pi is stored at seg ^ s5(pi),
-  // s5 = ((pi >> 1) & 1) | (((pi >> 3) & 1) << 1): the 8 rows a 32-lane half of a transposing read touches (pi .. pi+3
-  // and pi+8 .. pi+11) then fall in 8 different 32-byte bank groups.  pi >> 3 = the instruction's index in the slab.
-  const int ypix = lane >> 3;
-  const int ychk0 = (lane & 7) ^ (2 * ((ypix >> 1) & 1));
+  const int ypix = lane >> 3, ychk = lane & 7;                // dY: 8 pixels x 8 chunks
   auto x_plane_src = [&](int c, int pz) {                     // column c = (window, row quarter), input plane pz (halo coords)
     const int n = c / C::COLS, yq = c - n * C::COLS;
     return (const char*)(p.x + (((long long)n * (DEPTH + 2) + pz) * WP + 4 * yq) * (long long)(WP * CIN) + cs * 32);
@@ -117,22 +137,32 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
     return (const char*)(p.dy + (((long long)n * (DEPTH + 2) + z + 1) * WP + 4 * yq + 1) * (long long)(WP * COUT) + ns * 64);
   };
   auto dma_x = [&](const char* src, int slot, int j) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)(j * 16 + xpix) * (CIN * 2) + xchk * 16),
+    int lx = xpix;
+    asm volatile("" : "+v"(lx));                              // recompute the lane's offset per instruction (no hoisted tables)
+    const int P = j * 16 + lx, row = P / WP;                  // slab pixel, slab row: half ct of the pixel goes to ct ^ (row & 1)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(P * (CIN * 2) + (xchk ^ (2 * (row & 1))) * 16)),
                                      (__attribute__((address_space(3))) void*)(wp_smem + slot * C::XBUF + j * 1024), 16, 0, 0);
   };
   auto dma_y = [&](const char* src, int buf, int zl, int j) {
-    const int ychk = ychk0 ^ (4 * ((zl * C::DI + j) & 1));
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)(j * 8 + ypix) * (COUT * 2) + ychk * 16),
+    int ly = ypix;
+    asm volatile("" : "+v"(ly));
+    const int pi = j * 8 + ly, row = pi / WP, xs = pi - row * WP;         // slab pixel (x = xs - 1), slab row
+    const int sw = (((xs - 1) >> 1) & 1) | ((row & 1) << 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(pi * (COUT * 2) + (ychk ^ (2 * sw)) * 16)),
                                      (__attribute__((address_space(3))) void*)(wp_smem + C::DY_OFF + buf * C::DYBUF + zl * C::DYPLANE + j * 1024),
                                      16, 0, 0);
   };
-  // fetch input planes [pz0, pz0 + np) and the dY slab of group gq of column c; the instructions are dealt round-robin
-  auto fetch = [&](int c, int pz0, int np, int gq) {
+  // fetch what group (column c = col0 + kc, gq) needs and no earlier group of its column has fetched: input planes
+  // 0 .. ZS + 1 (gq = 0) or the ZS planes behind them, and its dY slab; the instructions are dealt round-robin.
+  // Input plane pz of the block's kc-th column lives in ring slot (kc (DEPTH + 2) + pz) % NXB.
+  auto fetch = [&](int kc, int gq) {
+    const int c = col0 + kc;
+    const int pz0 = gq == 0 ? 0 : gq * ZS + 2, np = gq == 0 ? ZS + 2 : ZS;
     const int nx = np * C::XI, total = nx + ZS * C::DI;
     for (int t = wave; t < total; t += 8) {
       if (t < nx) {
         const int k = t / C::XI, j = t - k * C::XI;
-        dma_x(x_plane_src(c, pz0 + k), (pz0 + k) % C::NXB, j);
+        dma_x(x_plane_src(c, pz0 + k), (kc * (DEPTH + 2) + pz0 + k) % NXB, j);
       } else {
         const int u = t - nx, zl = u / C::DI, j = u - zl * C::DI;
         dma_y(y_plane_src(c, gq * ZS + zl), gq & 1, zl, j);
@@ -146,85 +176,113 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (; col < col_end; ++col) {
-    // column prologue: planes 0 .. ZS + 1 and the first dY slab (not overlapped: the ring slots of the previous
-    // column's last planes are still in use until its last group is done)
-    fetch(col, 0, ZS + 2, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma clang loop unroll(disable)
-    for (int gq = 0; gq < C::NG; ++gq) {
-      const int z0 = gq * ZS;
-      if (gq + 1 < C::NG) fetch(col, z0 + ZS + 2, ZS, gq + 1);   // in flight while this group computes
-      // wave-uniform address parts of this wave's units: plane slab of (plane z0 + zl + kz), tap offset, channel tile
-      unsigned sa[7][2];
+  // read bases of a group: X unit i (tap tap0 + 4 i), plane zl of the group; dY output tile j
+  unsigned bx[7][ZS], by[4];
+  auto bases = [&](int kc, int gq) {
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        int tap = tap0 + 4 * i;
-        if (tap > 26) tap = 26;                               // the unit does not exist: computed, never stored
-        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-        const unsigned off = lds0 + (unsigned)((ky * WP + kx) * 64 + ct * 32);
+    for (int i = 0; i < 7; ++i) {
+      int tap = tap0 + 4 * i;
+      if (tap > 26) tap = 26;                                 // the unit does not exist: computed, never stored
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      unsigned lanepart = xl0;
+      asm volatile("" : "+v"(lanepart));                      // one v_xor per unit and group instead of a hoisted register each
+      lanepart ^= (unsigned)((ky & 1) << 5);
+      const unsigned off = lds0 + (unsigned)((ky * WP + kx) * 64);
 #pragma unroll
-        for (int zl = 0; zl < 2; ++zl) sa[i][zl] = off + (unsigned)(((z0 + zl + kz) % C::NXB) * C::XBUF);
-      }
-      const unsigned yb = lds0 + C::DY_OFF + (gq & 1) * C::DYBUF;
-      // fragments of step s: 8 dY reads (4 output tiles x 2 halves) and 14 X reads (7 units x 2 halves); the reads of step
-      // s + 1 are issued in front of the MFMAs of step s (two register sets)
-      auto reads = [&](int s, i32x2_wg (&bl)[4], i32x2_wg (&bh)[4], i32x2_wg (&al)[7], i32x2_wg (&ah)[7]) {
-        const unsigned y0 = yb + ya[s][0], y1 = yb + ya[s][1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bl[j] = wgp_tr_read(y0 ^ (unsigned)(j << 5));
-          bh[j] = wgp_tr_read(y1 ^ (unsigned)(j << 5));
-        }
-        const bool z0b = ZS == 2 && ((zlm >> (2 * s)) & 1u), z1b = ZS == 2 && ((zlm >> (2 * s + 1)) & 1u);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          al[i] = wgp_tr_read(xa[s][0] + (z0b ? sa[i][1] : sa[i][0]));
-          ah[i] = wgp_tr_read(xa[s][1] + (z1b ? sa[i][1] : sa[i][0]));
-        }
-      };
-      auto landed = [&](i32x2_wg (&bl)[4], i32x2_wg (&bh)[4], i32x2_wg (&al)[7], i32x2_wg (&ah)[7]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
-#pragma unroll
-        for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(al[i]), "+v"(ah[i]));
-      };
-      auto mmas = [&](const i32x2_wg (&bl)[4], const i32x2_wg (&bh)[4], const i32x2_wg (&al)[7], const i32x2_wg (&ah)[7]) {
-        f32x4 b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = __builtin_bit_cast(f32x4, (i32x4_wg){bl[j][0], bl[j][1], bh[j][0], bh[j][1]});
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const f32x4 a = __builtin_bit_cast(f32x4, (i32x4_wg){al[i][0], al[i][1], ah[i][0], ah[i][1]});
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<bf16_t>::step(acc[i][j], a, b[j]);
-        }
-      };
-      i32x2_wg bl0[4], bh0[4], al0[7], ah0[7], bl1[4], bh1[4], al1[7], ah1[7];
-      reads(0, bl0, bh0, al0, ah0);
-#pragma unroll
-      for (int s = 0; s < 7; s += 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        landed(bl0, bh0, al0, ah0);
-        if (s + 1 < 7) reads(s + 1, bl1, bh1, al1, ah1);
-        __builtin_amdgcn_sched_barrier(0);
-        mmas(bl0, bh0, al0, ah0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < 7) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          landed(bl1, bh1, al1, ah1);
-          if (s + 2 < 7) reads(s + 2, bl0, bh0, al0, ah0);
-          __builtin_amdgcn_sched_barrier(0);
-          mmas(bl1, bh1, al1, ah1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the next group's slabs have landed ...
-      __builtin_amdgcn_s_barrier();                           // ... for everybody, and everybody is done with this group's
+      for (int zl = 0; zl < ZS; ++zl)
+        bx[i][zl] = lanepart + (off + (unsigned)(((kc * (DEPTH + 2) + gq * ZS + zl + kz) % NXB) * C::XBUF));
     }
+    const unsigned yb = lds0 + C::DY_OFF + (gq & 1) * C::DYBUF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) by[j] = yl[j] + yb;
+  };
+  // fragments of step S: 8 dY reads (4 output tiles x 2 halves) and 14 X reads (7 units x 2 halves)
+  auto reads = [&](auto S, WgpFrags& f) {
+    constexpr int s = decltype(S)::value;
+    constexpr int u0 = 2 * s, u1 = 2 * s + 1;
+    constexpr int z0 = ZS == 2 ? u0 / 7 : 0, z1 = ZS == 2 ? u1 / 7 : 0;
+    constexpr int c0 = ZS == 2 ? 4 * (u0 % 7) : 4 * u0, c1 = ZS == 2 ? 4 * (u1 % 7) : 4 * u1;     // first column of the half
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.bl[j] = wgp_tr_read<z0 * C::DYPLANE + c0 * 128>(by[j]);
+      f.bh[j] = wgp_tr_read<z1 * C::DYPLANE + c1 * 128>(by[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      f.al[i] = wgp_tr_read<c0 * 64>(bx[i][z0]);
+      f.ah[i] = wgp_tr_read<c1 * 64>(bx[i][z1]);
+    }
+  };
+  auto landed = [&](WgpFrags& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(f.bl[j]), "+v"(f.bh[j]));
+#pragma unroll
+    for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(f.al[i]), "+v"(f.ah[i]));
+  };
+  auto mmas = [&](const WgpFrags& f) {
+    i32x4_wg b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = (i32x4_wg){f.bl[j][0], f.bl[j][1], f.bh[j][0], f.bh[j][1]};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const i32x4_wg a = (i32x4_wg){f.al[i][0], f.al[i][1], f.ah[i][0], f.ah[i][1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wgp_mfma(acc[i][j], a, b[j]);
+    }
+  };
+  // steps 0 .. 5 of a group whose step-0 fragments are in flight in fa; leaves step 6's in flight in fa
+  auto steps_0_5 = [&](WgpFrags& fa, WgpFrags& fb) {
+    landed(fa); reads(std::integral_constant<int, 1>{}, fb); __builtin_amdgcn_sched_barrier(0); mmas(fa); __builtin_amdgcn_sched_barrier(0);
+    landed(fb); reads(std::integral_constant<int, 2>{}, fa); __builtin_amdgcn_sched_barrier(0); mmas(fb); __builtin_amdgcn_sched_barrier(0);
+    landed(fa); reads(std::integral_constant<int, 3>{}, fb); __builtin_amdgcn_sched_barrier(0); mmas(fa); __builtin_amdgcn_sched_barrier(0);
+    landed(fb); reads(std::integral_constant<int, 4>{}, fa); __builtin_amdgcn_sched_barrier(0); mmas(fb); __builtin_amdgcn_sched_barrier(0);
+    landed(fa); reads(std::integral_constant<int, 5>{}, fb); __builtin_amdgcn_sched_barrier(0); mmas(fa); __builtin_amdgcn_sched_barrier(0);
+    landed(fb); reads(std::integral_constant<int, 6>{}, fa); __builtin_amdgcn_sched_barrier(0); mmas(fb); __builtin_amdgcn_sched_barrier(0);
+  };
+  // group G = (kc, gq) from its step-0 fragments in fa; its last step's MFMAs are issued behind the barrier that
+  // publishes group G + 1's slabs and behind the request for that group's step-0 fragments (into fb)
+  int kc = 0, gq = 0;
+  auto group = [&](int G, WgpFrags& fa, WgpFrags& fb) {
+    steps_0_5(fa, fb);
+    landed(fa);                                               // step 6's fragments: this group's slabs are no longer read
+    int kc1 = kc, gq1 = gq + 1;
+    if (gq1 == C::NG) { gq1 = 0; ++kc1; }
+    const bool more = G + 1 < n_groups;
+    if (more) bases(kc1, gq1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // group G + 1's slabs have landed (SEAMLESS, or same column) ...
+    __builtin_amdgcn_s_barrier();                             // ... for everybody, and everybody is done with group G's
+    if (!C::SEAMLESS && more && gq1 == 0) {
+      // no room to prefetch a column's first planes: they are fetched now, exposed (once per NG groups)
+      fetch(kc1, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (more) reads(std::integral_constant<int, 0>{}, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    mmas(fa);
+    __builtin_amdgcn_sched_barrier(0);
+    // the DMA issue (address arithmetic) sits behind the MFMAs, where only one fragment set is live
+    int kc2 = kc1, gq2 = gq1 + 1;                              // group G + 2
+    if (gq2 == C::NG) { gq2 = 0; ++kc2; }
+    if (G + 2 < n_groups && (C::SEAMLESS || gq2 != 0)) fetch(kc2, gq2);
+    kc = kc1; gq = gq1;
+  };
+
+  WgpFrags f0, f1;
+  fetch(0, 0);
+  bases(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  fetch(0, 1);                                                // NG >= 2: same column
+  reads(std::integral_constant<int, 0>{}, f0);
+#pragma clang loop unroll(disable)
+  for (int G = 0; G < n_groups; G += 2) {
+    group(G, f0, f1);
+    group(G + 1, f1, f0);
   }
 
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // the last MFMAs' results are in the registers
   // ---- dW[(tap * CIN + 32 cs + 16 ct + 4 g + r) * COUT + 64 ns + 16 j + fcol] += D[row 4 g + r][col fcol] ----
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
