@@ -196,22 +196,26 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
 #pragma unroll
     for (int j = 0; j < 4; ++j) by[j] = yl[j] + yb;
   };
-  // fragments of step S: 8 dY reads (4 output tiles x 2 halves) and 14 X reads (7 units x 2 halves)
-  auto reads = [&](auto S, WgpFrags& f) {
+  // fragment read r of step S (0-7: dY output tile r / 2, half r & 1; 8-21: X unit (r - 8) / 2, half r & 1)
+  auto read1 = [&](auto S, int r, WgpFrags& f) {
     constexpr int s = decltype(S)::value;
     constexpr int u0 = 2 * s, u1 = 2 * s + 1;
     constexpr int z0 = ZS == 2 ? u0 / 7 : 0, z1 = ZS == 2 ? u1 / 7 : 0;
     constexpr int c0 = ZS == 2 ? 4 * (u0 % 7) : 4 * u0, c1 = ZS == 2 ? 4 * (u1 % 7) : 4 * u1;     // first column of the half
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f.bl[j] = wgp_tr_read<z0 * C::DYPLANE + c0 * 128>(by[j]);
-      f.bh[j] = wgp_tr_read<z1 * C::DYPLANE + c1 * 128>(by[j]);
+    const int h = r & 1;
+    if (r < 8) {
+      const int j = r >> 1;
+      if (h == 0) f.bl[j] = wgp_tr_read<z0 * C::DYPLANE + c0 * 128>(by[j]);
+      else f.bh[j] = wgp_tr_read<z1 * C::DYPLANE + c1 * 128>(by[j]);
+    } else {
+      const int i = (r - 8) >> 1;
+      if (h == 0) f.al[i] = wgp_tr_read<c0 * 64>(bx[i][z0]);
+      else f.ah[i] = wgp_tr_read<c1 * 64>(bx[i][z1]);
     }
+  };
+  auto reads = [&](auto S, WgpFrags& f) {                     // all 22 of a step (the very first step of a block)
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      f.al[i] = wgp_tr_read<c0 * 64>(bx[i][z0]);
-      f.ah[i] = wgp_tr_read<c1 * 64>(bx[i][z1]);
-    }
+    for (int r = 0; r < 22; ++r) read1(S, r, f);
   };
   auto landed = [&](WgpFrags& f) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -220,28 +224,35 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
 #pragma unroll
     for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(f.al[i]), "+v"(f.ah[i]));
   };
-  auto mmas = [&](const WgpFrags& f) {
+  // the 28 MFMAs of a step on `cur`, with the 22 fragment reads of step S (of this group, or step 0 of the next one)
+  // into `nxt` issued one behind each of the first 22: the wave never stops feeding the matrix pipe to issue reads
+  // (a read burst in front of the MFMAs idles the pipe whenever the SIMD's two waves are in the same phase, and a
+  // barrier per group puts them there), and the last 6 MFMAs cover the last read's latency
+  auto step = [&](auto S, const WgpFrags& cur, WgpFrags& nxt) {
     i32x4_wg b[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = (i32x4_wg){f.bl[j][0], f.bl[j][1], f.bh[j][0], f.bh[j][1]};
+    for (int j = 0; j < 4; ++j) b[j] = (i32x4_wg){cur.bl[j][0], cur.bl[j][1], cur.bh[j][0], cur.bh[j][1]};
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      const i32x4_wg a = (i32x4_wg){f.al[i][0], f.al[i][1], f.ah[i][0], f.ah[i][1]};
+      const i32x4_wg a = (i32x4_wg){cur.al[i][0], cur.al[i][1], cur.ah[i][0], cur.ah[i][1]};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wgp_mfma(acc[i][j], a, b[j]);
+      for (int j = 0; j < 4; ++j) {
+        wgp_mfma(acc[i][j], a, b[j]);
+        if (4 * i + j < 22) read1(S, 4 * i + j, nxt);
+      }
     }
   };
   // steps 0 .. 5 of a group whose step-0 fragments are in flight in fa; leaves step 6's in flight in fa
   auto steps_0_5 = [&](WgpFrags& fa, WgpFrags& fb) {
-    landed(fa); reads(std::integral_constant<int, 1>{}, fb); __builtin_amdgcn_sched_barrier(0); mmas(fa); __builtin_amdgcn_sched_barrier(0);
-    landed(fb); reads(std::integral_constant<int, 2>{}, fa); __builtin_amdgcn_sched_barrier(0); mmas(fb); __builtin_amdgcn_sched_barrier(0);
-    landed(fa); reads(std::integral_constant<int, 3>{}, fb); __builtin_amdgcn_sched_barrier(0); mmas(fa); __builtin_amdgcn_sched_barrier(0);
-    landed(fb); reads(std::integral_constant<int, 4>{}, fa); __builtin_amdgcn_sched_barrier(0); mmas(fb); __builtin_amdgcn_sched_barrier(0);
-    landed(fa); reads(std::integral_constant<int, 5>{}, fb); __builtin_amdgcn_sched_barrier(0); mmas(fa); __builtin_amdgcn_sched_barrier(0);
-    landed(fb); reads(std::integral_constant<int, 6>{}, fa); __builtin_amdgcn_sched_barrier(0); mmas(fb); __builtin_amdgcn_sched_barrier(0);
+    landed(fa); step(std::integral_constant<int, 1>{}, fa, fb);
+    landed(fb); step(std::integral_constant<int, 2>{}, fb, fa);
+    landed(fa); step(std::integral_constant<int, 3>{}, fa, fb);
+    landed(fb); step(std::integral_constant<int, 4>{}, fb, fa);
+    landed(fa); step(std::integral_constant<int, 5>{}, fa, fb);
+    landed(fb); step(std::integral_constant<int, 6>{}, fb, fa);
   };
   // group G = (kc, gq) from its step-0 fragments in fa; its last step's MFMAs are issued behind the barrier that
-  // publishes group G + 1's slabs and behind the request for that group's step-0 fragments (into fb)
+  // publishes group G + 1's slabs, interleaved with the reads of that group's step-0 fragments (into fb)
   int kc = 0, gq = 0;
   auto group = [&](int G, WgpFrags& fa, WgpFrags& fb) {
     steps_0_5(fa, fb);
@@ -258,10 +269,7 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (more) reads(std::integral_constant<int, 0>{}, fb);
-    __builtin_amdgcn_sched_barrier(0);
-    mmas(fa);
-    __builtin_amdgcn_sched_barrier(0);
+    step(std::integral_constant<int, 0>{}, fa, fb);           // (after the last group the reads fetch nothing that is used)
     // the DMA issue (address arithmetic) sits behind the MFMAs, where only one fragment set is live
     int kc2 = kc1, gq2 = gq1 + 1;                              // group G + 2
     if (gq2 == C::NG) { gq2 = 0; ++kc2; }
