@@ -129,6 +129,35 @@ def test_c3d_backward_operators(gpu, case, autograd, dtype):
     assert all(rel(again[k], grads[k].numpy()) < 1e-4 for k in grads)      # fp32 atomics: order-dependent rounding only
 
 
+def test_patch_filter_gradients_odd_window_count(gpu):
+    """wgrad_patch.hip.h (conv2a, conv3a, conv3b; bf16): 5 windows give column ranges of unequal length per block
+    (35 / 70 columns over 8 / 64 ranges), empty ranges, and several seamless column changes per block."""
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    n = 5
+    p = syn.c3d_params(33)
+    rs = np.random.RandomState(34)
+    video = (rs.rand(n, 16, 112, 112, 3).astype(np.float32) - 0.5) * 2
+    g = rs.randn(n, 1024, 7, 7).astype(np.float32)
+    eng = C3DEngine(n, dtype='bf16', device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    eng.forward(torch.tensor(video, device=gpu))
+    eng.backward(d_features=torch.tensor(g, device=gpu))
+    grads = {k: v.cpu() for k, v in eng.grad_views().items()}
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        for i in (1, 2, 3):
+            name = NAMES[i]
+            x = ncdhw(eng.read_layer(i - 1, n).cpu().reshape((n,) + tuple(int(v) for v in torch_ref_out_shape(i - 1))))
+            dy = ncdhw(eng.read_grad_image(i, n).cpu())
+            shape = tuple(torch.tensor(p[name + '_w']).permute(4, 3, 0, 1, 2).shape)
+            dw = torch.nn.grad.conv3d_weight(x, shape, dy, padding=1).permute(2, 3, 4, 1, 0)
+            assert np.abs(dw.numpy()).max() > 0
+            assert rel(grads[name + '_w'].numpy(), dw.numpy()) < TOL_LOCAL['bf16'], ('wgrad', name)
+    finally:
+        torch.set_num_threads(old)
+
+
 def torch_ref_out_shape(i):
     """NDHWC extent of layer i's pooled output."""
     d, h = {0: (16, 56), 1: (8, 28), 2: (8, 28), 3: (4, 14), 4: (4, 14), 5: (2, 7), 6: (2, 7)}[i]
