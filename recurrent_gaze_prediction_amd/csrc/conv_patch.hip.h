@@ -55,7 +55,15 @@ struct ConvPatchParams {
   unsigned char* argmax;  // pooled layers, training plans: [n][D/2][HW/2][HW/2][NOUT] index (dz*4 + dy*2 + dx) of the first maximum
   const bf16_t* mask;     // DGRAD kernels: forward activation in the layout of `out`; the result is kept where it is > 0
   int n_windows;
+  int ablate;             // dev builds (RGP_CP_ABLATE, timing only, results garbage): 1 plane fetches from one L2-resident
+                          // slab, 2 no epilogue, 4 epilogue without its global stores, 8 filter slabs from one L2-resident slab
 };
+
+#ifdef RGP_DEV_KNOBS
+#define RGP_CP_ABL(p, bit) (((p).ablate & (bit)) != 0)
+#else
+#define RGP_CP_ABL(p, bit) false
+#endif
 
 template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCfg {
   static constexpr int WP = HW + 2;                       // padded row: 58 / 30 pixels
@@ -140,6 +148,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   auto plane_src = [&](int tile, int cc, int k) -> const char* {
     const int n = tile / C::TILES_PER_WINDOW, r = tile - n * C::TILES_PER_WINDOW;
     const int zp = r / C::YT, yp = r - zp * C::YT;
+    if (RGP_CP_ABL(p, 1)) return (const char*)(p.in + (long long)(blockIdx.x & 7) * C::IN_PLANE);
     return (const char*)(p.in + (long long)n * C::IN_IMG + (long long)(2 * zp + k) * C::IN_PLANE + (4 * yp) * C::IN_ROW + cc * 32);
   };
   // this wave's PPW of a plane slab's DMA instructions: 16 pixels x 64 B each
@@ -163,7 +172,8 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #pragma unroll
   for (int u = 0; u < C::BPW; ++u) b_src[u] = (const char*)(p.wp + (long long)b_row(wave * C::BPW + u) * C::K) + bchk * 16;
   auto dma_b = [&](int slot, int cc, int tap) {
-    const int koff = (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2;
+    int koff = (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2;
+    if (RGP_CP_ABL(p, 8)) koff = 0;
 #pragma unroll
     for (int u = 0; u < C::BPW; ++u)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[u] + koff),
@@ -307,7 +317,12 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 
     const int tn = tile / C::TILES_PER_WINDOW, tr = tile - tn * C::TILES_PER_WINDOW;
     const int zp = tr / C::YT, yp = tr - zp * C::YT;
-    if constexpr (POOL) {
+    if (RGP_CP_ABL(p, 2)) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (POOL) {
       // ---- epilogue: pool in registers (a lane holds the 4 members of a window with its dz, lane ^ 16 the other 4),
       // bias + ReLU, pooled bf16 tile (and arg-max codes) through LDS, 16-byte (8-byte) stores ----
       bf16_t* stg = (bf16_t*)(cp_smem + C::STG_OFF);
@@ -343,7 +358,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int w = tid / C::CGN + (512 / C::CGN) * k;      // pooling window of the tile
-        if (w < C::WIN) {
+        if (w < C::WIN && !RGP_CP_ABL(p, 4)) {
           const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
           *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = *(const u32x4*)(stg + w * C::STG_LD + cg * 8);
           if constexpr (ARGMAX) *(uint2*)(abase + (ypl * (HW / 2) + xp) * NOUT + cg * 8) = *(const uint2*)(stga + w * C::STG_LD + cg * 8);

@@ -54,6 +54,7 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
   p.mask = nullptr;
   p.n_windows = n;
+  p.ablate = dev_knob("RGP_CP_ABLATE", 0);
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
   auto kern = conv_patch_bf16_kernel<CIN, NOUT, HW, DEPTH, POOL, ARGMAX>;
@@ -74,6 +75,7 @@ static int run_conv_patch14(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
   p.mask = nullptr;
   p.n_windows = n;
+  p.ablate = 0;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
   auto kern = conv_patch14_bf16_kernel<CIN, POOL, ARGMAX>;
@@ -103,6 +105,7 @@ int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.argmax = nullptr;
   p.mask = (const bf16_t*)(c->ws + c->act_off[layer]);
   p.n_windows = n;
+  p.ablate = 0;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
   if (layer == 1 || layer == 2) {
