@@ -41,6 +41,9 @@
 
 #include "igemm.hip.h"
 
+#ifndef RGP_MMA_ORDER
+#define RGP_MMA_ORDER 1     // 1: filter fragment outermost in a step (7 consecutive MFMAs share it; 0: the activation fragment, 4): -0.5 % wall
+#endif
 #ifndef RGP_PLANE_AUX
 #define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured)
 #endif
@@ -290,10 +293,17 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- COMPUTE ----------------
         __builtin_amdgcn_s_setprio(1);
+#if RGP_MMA_ORDER == 1
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int i = 0; i < 7; ++i) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
+#else
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
+#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
