@@ -101,7 +101,7 @@ int forward_chunk(rgp_c3d* c, const float* video, const FrameSrc* fs, int n, flo
 template <typename T>
 int set_weights_impl(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
   for (int i = 0; i < 8; ++i) {
-    RGP_HIP(hipMemsetAsync(c->ws + c->L[i].w_off, 0, c->L[i].w_bytes(c->dtype), s));
+    // (no memset: the packed area is zero from bind time outside the positions the pack writes)
     RGP_TRY(pack_filter<T>(c->L[i], w->w[i], c->ws, kLayers[i].cout, 0, s));
     c->bias[i] = w->b[i];
   }

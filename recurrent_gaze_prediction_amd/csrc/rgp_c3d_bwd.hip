@@ -329,7 +329,6 @@ int c3d_bwd_upload(rgp_c3d* c, hipStream_t s) {
 int c3d_bwd_pack(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
   for (int i = 1; i < 8; ++i) {
     const ConvDesc& d = c->B[i].dg;
-    RGP_HIP(hipMemsetAsync(c->ws + d.w_off, 0, d.w_bytes(c->dtype), s));
     if (c->dtype == RGP_BF16) RGP_TRY(pack_filter<bf16_t>(d, w->w[i], c->ws, kLayers[i].cin, 0, s));
     else RGP_TRY(pack_filter<float>(d, w->w[i], c->ws, kLayers[i].cin, 0, s));
   }

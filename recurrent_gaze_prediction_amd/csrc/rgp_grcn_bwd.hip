@@ -93,14 +93,33 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   auto Fp = [&](const Buf& x) { return (float*)(ws + x.off); };
   auto Tp = [&](const Buf& x) { return (T*)(ws + x.off); };
 
-  // zero the gradients that are accumulated with atomics
-  RGP_HIP(hipMemsetAsync((void*)gr->proj_c3d_W, 0, (size_t)1024 * P * 4, s));
-  RGP_HIP(hipMemsetAsync((void*)gr->proj_c3d_b, 0, (size_t)P * 4, s));
+  // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
+  // slices of one flat buffer (engine.py: flat_grads), else one per tensor
+  {
+    struct Z { const float* q; size_t n; };
+    const Z z[] = {{gr->proj_c3d_W, (size_t)1024 * P}, {gr->proj_c3d_b, (size_t)P},
+                   {gr->gru_Wz, (size_t)9 * P * S}, {gr->gru_Wr, (size_t)9 * P * S}, {gr->gru_W, (size_t)9 * P * S},
+                   {gr->gru_Uz, (size_t)9 * S * S}, {gr->gru_Ur, (size_t)9 * S * S}, {gr->gru_U, (size_t)9 * S * S},
+                   {gr->up_weight1, (size_t)25 * 64 * S}, {gr->up_weight2, (size_t)25 * 32 * 64}};
+    const float* lo = z[0].q;
+    const float* hi = z[0].q + z[0].n;
+    for (const Z& e : z) { lo = std::min(lo, e.q); hi = std::max(hi, e.q + e.n); }
+    // every other gradient of the struct is fully overwritten later in this call, so a range that also covers them
+    // (bn_gamma/beta, up_weight3, out_W, out_b, biases) may be cleared as a whole -- but only memory the struct owns:
+    const float* all_lo = lo;
+    const float* all_hi = hi;
+    const Z rest[] = {{gr->bn_gamma, (size_t)g->T * S}, {gr->bn_beta, (size_t)g->T * S}, {gr->up_weight3, (size_t)49 * 12 * 32},
+                      {gr->out_W, 12}, {gr->out_b, 1}};
+    size_t owned = 0;
+    for (const Z& e : z) owned += e.n;
+    for (const Z& e : rest) { all_lo = std::min(all_lo, e.q); all_hi = std::max(all_hi, e.q + e.n); owned += e.n; }
+    if ((size_t)(all_hi - all_lo) == owned) {
+      RGP_HIP(hipMemsetAsync((void*)all_lo, 0, owned * 4, s));
+    } else {
+      for (const Z& e : z) RGP_HIP(hipMemsetAsync((void*)e.q, 0, e.n * 4, s));
+    }
+  }
   RGP_HIP(hipMemsetAsync(ws + b->dE.off, 0, (size_t)P * sizeof(T), s));                    // dE's zero row
-  for (const float* q : {gr->gru_Wz, gr->gru_Wr, gr->gru_W}) RGP_HIP(hipMemsetAsync((void*)q, 0, (size_t)9 * P * S * 4, s));
-  for (const float* q : {gr->gru_Uz, gr->gru_Ur, gr->gru_U}) RGP_HIP(hipMemsetAsync((void*)q, 0, (size_t)9 * S * S * 4, s));
-  RGP_HIP(hipMemsetAsync((void*)gr->up_weight1, 0, (size_t)25 * 64 * S * 4, s));
-  RGP_HIP(hipMemsetAsync((void*)gr->up_weight2, 0, (size_t)25 * 32 * 64 * 4, s));
   RGP_HIP(hipMemsetAsync(ws + b->dgp.off, 0, b->dgp.bytes, s));
 
   if (ext_dy) {
@@ -279,7 +298,7 @@ int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   GrcnBwd* b = g->bwd;
   char* ws = g->ws;
   const int S = g->S, P = g->P;
-  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
+  // (no memset: the areas are zero from bind time outside the positions a pack writes, rgp_grcn.hip set_weights_impl)
   RGP_TRY(pack_filter<T>(b->b_px, w->proj_c3d_W, ws, 512, 0, s));            // d = 0: feature channels 0, 2, 4, ...
   RGP_TRY(pack_filter<T>(b->b_px, w->proj_c3d_W + P, ws, 512, 512, s));      // d = 1: feature channels 1, 3, 5, ...
   RGP_TRY(pack_filter<T>(b->b_d2, w->up_weight2, ws, 64, 0, s));
