@@ -290,7 +290,8 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
     group(G + 1, f1, f0);
   }
 
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // the last MFMAs' results are in the registers
+  // the last step's (unused) fragment reads have returned; the last MFMAs' results are in the registers
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   // ---- dW[(tap * CIN + 32 cs + 16 ct + 4 g + r) * COUT + 64 ns + 16 j + fcol] += D[row 4 g + r][col fcol] ----
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
