@@ -7,6 +7,7 @@ adds a draining `s_waitcnt vmcnt(0)` before the fragment reads depends on its re
 (a global load consumed only under a condition leaves "maybe pending" registers; re-using one of them inside the loop
 forces the wait) -- it appeared and disappeared with unrelated edits during round 1.  Run after touching
 igemm_stagger.hip.h / igemm_wide.hip.h / igemm.hip.h epilogues:   python scripts/check_isa_waits.py
+Also checks the wgrad_patch.hip.h kernels (no scratch access between their MFMAs, accumulation in place).
 """
 import os, subprocess, sys, tempfile
 
@@ -39,6 +40,35 @@ def stray_waits(body):
     return bad
 
 
+def wgrad_patch_kernels(asm):
+    lines = asm.split('\n')
+    for st, l in enumerate(lines):
+        if l.startswith('_ZN3rgpL23wgrad_patch_bf16_kernel') and '@' in l:
+            end = next(i for i in range(st, len(lines)) if 's_endpgm' in lines[i])
+            yield l.split(':')[0], lines[st:end]
+
+
+def wgrad_patch_faults(body):
+    """wgrad_patch.hip.h: between the first and the last MFMA there must be no scratch access (a spill inside the group
+    loop waits on vmcnt and with it on the slab DMA in flight: +10 % when it happened), every MFMA must accumulate in
+    place, and no compiler-inserted vmcnt wait may sit between two MFMAs of a step (the kernel's own are vmcnt(0) in
+    front of a barrier)."""
+    mf = [i for i, l in enumerate(body) if 'v_mfma' in l]
+    faults = []
+    if not mf:
+        return ['no MFMA found']
+    loop = body[mf[0]:mf[-1] + 1]
+    if any('scratch_' in l for l in loop):
+        faults.append('scratch access inside the MFMA region')
+    for l in loop:
+        if 'v_mfma' in l:
+            ops = [o.strip() for o in l.split('v_mfma_f32_16x16x32_bf16')[1].split(',')]
+            if ops[0] != ops[3]:
+                faults.append('MFMA not in place: ' + l.strip())
+                break
+    return faults
+
+
 def main():
     rc = 0
     for tu in ('rgp_c3d.hip', 'rgp_c3d_bwd.hip'):
@@ -56,6 +86,16 @@ def main():
                 print('STRAY WAIT', tu, name[:90], bad[:2])
         print('%s: %d staggered / wide kernels, %d with a compiler wait in front of the fragment reads' % (tu, n, nbad))
         rc |= nbad > 0
+        nw = nwbad = 0
+        for name, body in wgrad_patch_kernels(asm):
+            nw += 1
+            faults = wgrad_patch_faults(body)
+            if faults:
+                nwbad += 1
+                print('WGRAD_PATCH', name[:90], faults)
+        if nw:
+            print('%s: %d wgrad_patch kernels, %d with spills in the loop or renamed accumulators' % (tu, nw, nwbad))
+        rc |= nwbad > 0
     sys.exit(rc)
 
 
