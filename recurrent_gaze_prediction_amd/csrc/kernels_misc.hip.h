@@ -84,6 +84,71 @@ __global__ __launch_bounds__(256) void pack_filter_tiled_kernel(const float* __r
   }
 }
 
+// Several packs in ONE launch (the head re-packs 34 filters after every optimizer step: at config 4's shape the step is
+// launch-bound and each of those launches cost ~4 us for a few KB of work).  A job is the argument list of one of the
+// two kernels above; the table travels as a kernel argument.  Block b belongs to the job j with first[j] <= b < first[j+1].
+struct PackJob {
+  const float* src;
+  void* dst;
+  const int* tap_src;
+  long long s_tap, s_n, s_c;
+  int ntaps, cin_k, cin_src, n_rows, row0, K, k0, grouped, row_step, chunk_major;
+  int tiled, gx, gy;                 // tiled: grid of the job = gx x gy x ntaps blocks; else `gx` grid-stride blocks
+};
+constexpr int PACK_MAX_JOBS = 32;
+struct PackJobTable {
+  PackJob job[PACK_MAX_JOBS];
+  int first[PACK_MAX_JOBS + 1];
+  int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_filter_batch_kernel(const PackJobTable t) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.first[j + 1]) ++j;
+  const PackJob& q = t.job[j];
+  const int b = blockIdx.x - t.first[j];
+  T* dst = (T*)q.dst;
+  if (q.tiled) {
+    const int bx = b % q.gx, by = (b / q.gx) % q.gy, tap = b / (q.gx * q.gy);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = bx * 32, n0 = by * 32;
+    const int ts = q.tap_src ? q.tap_src[tap] : tap;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, n = n0 + tx;
+      float v = 0.f;
+      if (ts >= 0 && c < q.cin_src && n < q.n_rows) v = q.src[ts * q.s_tap + n + c * q.s_c];
+      tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    const int c = c0 + tx;
+    if (c >= q.cin_k) return;
+    const int col = q.chunk_major ? (c / q.chunk_major) * (q.ntaps * q.chunk_major) + tap * q.chunk_major + (c % q.chunk_major)
+                                  : tap * q.cin_k + q.k0 + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = n0 + ty + 8 * k;
+      if (n < q.n_rows) dst[(long long)(q.row0 + n * q.row_step) * q.K + col] = Elem<T>::to(tile[tx][ty + 8 * k]);
+    }
+    return;
+  }
+  const long long total = (long long)q.n_rows * q.ntaps * q.cin_k;
+  for (long long i = (long long)b * 256 + threadIdx.x; i < total; i += (long long)q.gx * 256) {
+    const int c = (int)(i % q.cin_k);
+    const int tap = (int)((i / q.cin_k) % q.ntaps);
+    const int n = (int)(i / ((long long)q.cin_k * q.ntaps));
+    if (q.grouped && c >= q.cin_src) continue;
+    const int ts = q.tap_src ? q.tap_src[tap] : tap;
+    float v = 0.f;
+    if (ts >= 0 && c < q.cin_src) v = q.src[ts * q.s_tap + n * q.s_n + c * q.s_c];
+    const int col = q.chunk_major ? (c / q.chunk_major) * (q.ntaps * q.chunk_major) + tap * q.chunk_major + (c % q.chunk_major)
+                                  : tap * q.cin_k + q.k0 + c;
+    dst[(long long)(q.row0 + n * q.row_step) * q.K + col] = Elem<T>::to(v);
+  }
+}
+
 // Exact algebraic fold of the 7x7 transposed conv (12 channels) with the 12->1
 // projection (gaze_grcn.py:353-361): G[tap][c] = sum_o F[tap][o][c] * out_W[o].
 static __global__ void fold_head_filter_kernel(const float* __restrict__ f, const float* __restrict__ out_w,

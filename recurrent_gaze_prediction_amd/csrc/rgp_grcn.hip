@@ -213,30 +213,32 @@ template <typename T>
 int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   char* ws = g->ws;
   const int S = g->S, P = g->P;
+  PackBatch<T> pk(ws, s);       // every pack of this call in one launch, behind the fold / Toeplitz kernels it reads from
   // (the packed-filter areas were zeroed with the workspace at bind time and a pack writes the same positions every
   // time: their channel / row padding stays zero without a memset per call -- 17 launches per optimizer step)
-  RGP_TRY(pack_filter<T>(g->proj, w->proj_c3d_W, ws, P, 0, s));
-  RGP_TRY(pack_filter<T>(g->proj_rows, w->proj_c3d_W, ws, P, 0, s));
-  RGP_TRY(pack_filter<T>(g->xconv, w->gru_Wz, ws, S, 0, s));
-  RGP_TRY(pack_filter<T>(g->xconv, w->gru_Wr, ws, S, S, s));
-  RGP_TRY(pack_filter<T>(g->xconv, w->gru_W, ws, S, 2 * S, s));
-  RGP_TRY(pack_filter<T>(g->gzr, w->gru_Uz, ws, S, 0, s));
-  RGP_TRY(pack_filter<T>(g->gzr, w->gru_Ur, ws, S, S, s));
-  RGP_TRY(pack_filter<T>(g->gc, w->gru_U, ws, S, 0, s));
+  RGP_TRY(pk.add(g->proj, w->proj_c3d_W, P, 0));
+  RGP_TRY(pk.add(g->proj_rows, w->proj_c3d_W, P, 0));
+  RGP_TRY(pk.add(g->xconv, w->gru_Wz, S, 0));
+  RGP_TRY(pk.add(g->xconv, w->gru_Wr, S, S));
+  RGP_TRY(pk.add(g->xconv, w->gru_W, S, 2 * S));
+  RGP_TRY(pk.add(g->gzr, w->gru_Uz, S, 0));
+  RGP_TRY(pk.add(g->gzr, w->gru_Ur, S, S));
+  RGP_TRY(pk.add(g->gc, w->gru_U, S, 0));
   for (ConvDesc& d : g->d1) {
-    RGP_TRY(pack_filter<T>(d, w->up_weight1, ws, 64, 0, s));
+    RGP_TRY(pk.add(d, w->up_weight1, 64, 0));
   }
   for (ConvDesc& d : g->d2) {
-    RGP_TRY(pack_filter<T>(d, w->up_weight2, ws, 32, 0, s));
+    RGP_TRY(pk.add(d, w->up_weight2, 32, 0));
   }
   float* gf = (float*)(ws + g->gfold.off);
   fold_head_filter_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(w->up_weight3, w->out_W, gf, 49, 12, 32);
   RGP_HIP(hipGetLastError());
-  RGP_TRY(pack_filter<T>(g->d3, gf, ws, 1, 0, s));
+  RGP_TRY(pk.add(g->d3, gf, 1, 0));
   toeplitz_head_filter_kernel<<<(7 * 16 * 704 + 255) / 256, 256, 0, s>>>(gf, w->out_b, (float*)(ws + g->gtoep.off),
                                                                           (float*)(ws + g->bias16.off));
   RGP_HIP(hipGetLastError());
-  RGP_TRY(pack_filter<T>(g->d3t, (const float*)(ws + g->gtoep.off), ws, 16, 0, s));
+  RGP_TRY(pk.add(g->d3t, (const float*)(ws + g->gtoep.off), 16, 0));
+  RGP_TRY(pk.flush());
   g->bn_gamma = w->bn_gamma;
   g->bn_beta = w->bn_beta;
   g->proj_b = w->proj_c3d_b;

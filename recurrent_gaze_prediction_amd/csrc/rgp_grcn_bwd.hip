@@ -298,17 +298,19 @@ int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   GrcnBwd* b = g->bwd;
   char* ws = g->ws;
   const int S = g->S, P = g->P;
+  PackBatch<T> pk(ws, s);                                                     // one launch for the ten packs
   // (no memset: the areas are zero from bind time outside the positions a pack writes, rgp_grcn.hip set_weights_impl)
-  RGP_TRY(pack_filter<T>(b->b_px, w->proj_c3d_W, ws, 512, 0, s));            // d = 0: feature channels 0, 2, 4, ...
-  RGP_TRY(pack_filter<T>(b->b_px, w->proj_c3d_W + P, ws, 512, 512, s));      // d = 1: feature channels 1, 3, 5, ...
-  RGP_TRY(pack_filter<T>(b->b_d2, w->up_weight2, ws, 64, 0, s));
-  RGP_TRY(pack_filter<T>(b->b_d1, w->up_weight1, ws, S, 0, s));
-  RGP_TRY(pack_filter<T>(b->b_c, w->gru_U, ws, S, 0, s));
-  RGP_TRY(pack_filter<T>(b->b_zr, w->gru_Uz, ws, S, 0, s, 0, 1));
-  RGP_TRY(pack_filter<T>(b->b_zr, w->gru_Ur, ws, S, 0, s, S, 1));
-  RGP_TRY(pack_filter<T>(b->b_x, w->gru_Wz, ws, P, 0, s, 0, 1));
-  RGP_TRY(pack_filter<T>(b->b_x, w->gru_Wr, ws, P, 0, s, S, 1));
-  RGP_TRY(pack_filter<T>(b->b_x, w->gru_W, ws, P, 0, s, 2 * S, 1));
+  RGP_TRY(pk.add(b->b_px, w->proj_c3d_W, 512, 0));            // d = 0: feature channels 0, 2, 4, ...
+  RGP_TRY(pk.add(b->b_px, w->proj_c3d_W + P, 512, 512));      // d = 1: feature channels 1, 3, 5, ...
+  RGP_TRY(pk.add(b->b_d2, w->up_weight2, 64, 0));
+  RGP_TRY(pk.add(b->b_d1, w->up_weight1, S, 0));
+  RGP_TRY(pk.add(b->b_c, w->gru_U, S, 0));
+  RGP_TRY(pk.add(b->b_zr, w->gru_Uz, S, 0, 0, 1));
+  RGP_TRY(pk.add(b->b_zr, w->gru_Ur, S, 0, S, 1));
+  RGP_TRY(pk.add(b->b_x, w->gru_Wz, P, 0, 0, 1));
+  RGP_TRY(pk.add(b->b_x, w->gru_Wr, P, 0, S, 1));
+  RGP_TRY(pk.add(b->b_x, w->gru_W, P, 0, 2 * S, 1));
+  RGP_TRY(pk.flush());
   // Gp[u,v,c] = G[6-u,6-v,c] in fp32 for the folded-filter dgrad (G itself is in g->gfold)
   // (49*32 elements; reuse the pack kernel with T=float semantics is overkill: tiny copy kernel)
   return RGP_OK;

@@ -177,6 +177,42 @@ int pack_filter(const ConvDesc& d, const float* src, char* ws, int n_rows, int r
   return RGP_OK;
 }
 
+// pack_filter() calls collected into launches of up to PACK_MAX_JOBS jobs (same arguments, same kernel choice per job)
+template <typename T>
+struct PackBatch {
+  PackJobTable t;
+  char* ws;
+  hipStream_t s;
+  int blocks = 0;
+  PackBatch(char* ws_, hipStream_t s_) : ws(ws_), s(s_) { t.n = 0; t.first[0] = 0; }
+  int flush() {
+    if (t.n == 0) return RGP_OK;
+    pack_filter_batch_kernel<T><<<blocks, 256, 0, s>>>(t);
+    RGP_HIP(hipGetLastError());
+    t.n = 0; blocks = 0; t.first[0] = 0;
+    return RGP_OK;
+  }
+  int add(const ConvDesc& d, const float* src, int n_rows, int row0, int k0 = 0, int grouped = 0, int row_step = 1) {
+    if (t.n == PACK_MAX_JOBS) RGP_TRY(flush());
+    PackJob& q = t.job[t.n];
+    q.src = src; q.dst = ws + d.w_off; q.tap_src = (const int*)(ws + d.tap_src_off);
+    q.s_tap = d.s_tap; q.s_n = d.s_n; q.s_c = d.s_c;
+    q.ntaps = d.pack_taps; q.cin_k = d.cin_k; q.cin_src = d.cin_src; q.n_rows = n_rows; q.row0 = row0; q.K = d.K; q.k0 = k0;
+    q.grouped = grouped; q.row_step = row_step; q.chunk_major = d.chunk_major;
+    int nb;
+    if (!grouped && d.s_n == 1 && d.cin_k >= 32 && n_rows >= 32) {      // as pack_filter(): tiled transpose
+      q.tiled = 1; q.gx = (d.cin_k + 31) / 32; q.gy = (n_rows + 31) / 32;
+      nb = q.gx * q.gy * d.pack_taps;
+    } else {
+      const long long total = (long long)n_rows * d.pack_taps * d.cin_k;
+      q.tiled = 0; q.gy = 1; q.gx = nb = (int)std::min<long long>((total + 255) / 256, 4096);
+    }
+    blocks += nb;
+    t.first[++t.n] = blocks;
+    return RGP_OK;
+  }
+};
+
 // ---- launch dispatch -------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
 int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
