@@ -26,3 +26,20 @@ def test_rccl_one_rank_group_runs_the_reducer(gpu):
     assert abs(out['loss_after_2_steps'][0] - out['loss_after_2_steps'][1]) < 1e-2 * abs(out['loss_after_2_steps'][0]), out
     # the head's flat buffer + the eight conv layers' buckets went through RCCL every step
     assert out['bytes_reduced_per_step'] > 100e6, out
+
+
+def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
+    """World size 2 with the real engines (gloo, both ranks on this GPU): tests/dp2_gpu_child.py."""
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp2_gpu_child.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29547', child],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert abs(out['loss_dp_mean'] - out['loss_ref']) < 1e-5 * abs(out['loss_ref']), out
+    assert out['grad_rms_rel'] < 1e-5 and out['grad_max_rel'] < 1e-4, out
+    assert abs(out['gnorm_dp'] - out['gnorm_ref']) < 1e-4 * out['gnorm_ref'], out
+    assert out['param_step_agree'] > 0.99, out
+    assert out['bytes_reduced'] > 2 * 100e6, out                 # two steps' worth of buckets went through the group
