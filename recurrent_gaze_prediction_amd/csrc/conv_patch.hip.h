@@ -31,7 +31,8 @@
 //    runs of 4 consecutive pixels (256 B) on rows whose pitch is 58*64 = 128 (mod 256), and the plane buffers start
 //    at 32 (k & 1) (mod 256): every 16-lane group of the read covers the 64 banks exactly once.  No swizzle.
 //  * rows are ordered (pooling window, dz, dy, dx): a lane's 4 accumulator registers + the lane 16 further hold one
-//    window, pool2 is a max3 tree and one ds_swizzle; the pooled 56 x 128 tile goes through LDS for 16-byte stores.
+//    window, pool2 is a max3 tree and one ds_swizzle; the pooled 56 x 128 tile goes through LDS (8-byte writes of 4
+//    adjacent channels per lane) for 16-byte stores.
 //    (The stores sit in the same vmcnt queue as the DMA: the first two counted waits of the next tile also wait for
 //    them -- conservative, never early.)
 //  * schedule: the two-group staggered loop of igemm_wide.hip.h (waves 0-3 / 4-7, partners on a SIMD, half a step
@@ -112,10 +113,12 @@ static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
   return v;
 }
 
-// POOL: 2x2x2 max-pool epilogue (conv2a, conv3b).  !POOL (conv3a): the same tiles -- the row order (2x2x2 blocks of
-// positions) is immaterial to a convolution -- stored un-pooled; MFMA column 16 j + c of a wave then carries channel
-// 64 wn + 4 c + j (the filter slab is fetched in that row order), so a lane holds 4 adjacent channels of a position and
-// stores 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
+// In every variant MFMA column 16 j + c of a wave carries channel 64 wn + 4 c + j (the filter slab is fetched in that row
+// order), so a lane holds 4 adjacent channels of a position.
+// POOL: 2x2x2 max-pool epilogue (conv2a, conv3b): the lane's four pooled channels of a window are staged with one 8-byte
+// LDS write (their arg-max codes with one 4-byte write; four 2-byte writes each before: conv2a -1.5 %).
+// !POOL (conv3a): the same tiles -- the row order (2x2x2 blocks of positions) is immaterial to a convolution -- stored
+// un-pooled: 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
 // DGRAD (!POOL): the same convolution as the input gradient of a layer (in = dY before pooling, halo-padded; filter =
 // the rotated, in/out-swapped one of the backward plan): no bias, no ReLU, the result masked by the forward activation.
 // DENSE (DGRAD only): the output is the dense, un-masked [n][D*HW*HW][NOUT] image the un-pool kernel consumes (gradient
@@ -170,7 +173,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
   // filter row (output channel) behind row brow of 1-KB block blk: blk * 16 + brow, or (!POOL) wave blk / NI, column
   // tile blk % NI: channel 16 NI (blk / NI) + NI brow + blk % NI (rows >= NOUT of a 64-channel filter are the packing's zeros)
-  auto b_row = [&](int blk) { return POOL ? blk * 16 + brow : (blk / NI) * (16 * NI) + brow * NI + (blk % NI); };
+  auto b_row = [&](int blk) { return (blk / NI) * (16 * NI) + brow * NI + (blk % NI); };
   const char* b_src[C::BPW];
 #pragma unroll
   for (int u = 0; u < C::BPW; ++u) b_src[u] = (const char*)(p.wp + (long long)b_row(wave * C::BPW + u) * C::K) + bchk * 16;
@@ -199,7 +202,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   const int cg = tid % C::CGN;                                // POOL epilogue, store pass: this thread's 8 output channels
   float b4[NI];                                               // bias of this lane's NI MFMA columns
 #pragma unroll
-  for (int q = 0; q < NI; ++q) b4[q] = DGRAD ? 0.f : p.bias[POOL ? wn * 64 + q * 16 + frow : wn * (16 * NI) + frow * NI + q];
+  for (int q = 0; q < NI; ++q) b4[q] = DGRAD ? 0.f : p.bias[wn * (16 * NI) + frow * NI + q];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -338,11 +341,14 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
       bf16_t* stg = (bf16_t*)(cp_smem + C::STG_OFF);
       unsigned char* stga = (unsigned char*)(cp_smem + C::STGA_OFF);
 #pragma unroll
-      for (int i = 0; i < 7; ++i)
+      for (int i = 0; i < 7; ++i) {
+        // MFMA column frow of n-tile j carries channel 64 wn + 4 frow + j (b_row): the lane's four pooled values of a
+        // window are adjacent channels -- one 8-byte LDS write (one 4-byte write of codes) instead of four 2-byte ones
+        unsigned short pv[4];
+        unsigned pc = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 c = acc[i][j];
-          const int so = (2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + j * 16 + frow;
           if constexpr (ARGMAX) {
             float best = c[0];
             int idx = 0;
@@ -351,16 +357,24 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
             if (c[3] > best) { best = c[3]; idx = 3; }
             const float ob = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, best), 0x401F));   // lane ^ 16
             const int oi = __builtin_amdgcn_ds_swizzle(idx, 0x401F);
-            if ((fk & 1) == 0) {                               // this lane: dz = 0 (members 0 .. 3), the other: dz = 1
-              stg[so] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
-              stga[so] = (unsigned char)(ob > best ? oi + 4 : idx);
-            }
+            // this lane: dz = 0 (members 0 .. 3), the other: dz = 1
+            pv[j] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
+            pc |= (unsigned)(ob > best ? oi + 4 : idx) << (8 * j);
           } else {
             const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
             const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-            if ((fk & 1) == 0) stg[so] = f2bf(fmaxf(fmaxf(x, y) + b4[j], 0.f));
+            pv[j] = f2bf(fmaxf(fmaxf(x, y) + b4[j], 0.f));
           }
         }
+        if ((fk & 1) == 0) {
+          const int so = (2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + 4 * frow;
+          uint2 o;
+          o.x = (unsigned)pv[0] | ((unsigned)pv[1] << 16);
+          o.y = (unsigned)pv[2] | ((unsigned)pv[3] << 16);
+          *(uint2*)(stg + so) = o;
+          if constexpr (ARGMAX) *(unsigned*)(stga + so) = pc;
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
       __builtin_amdgcn_s_barrier();
       bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
