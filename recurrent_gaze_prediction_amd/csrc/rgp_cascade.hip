@@ -128,28 +128,29 @@ int set_weights_impl(rgp_cascade* g, const rgp_cascade_weights* w, hipStream_t s
   RGP_TRY(rgp_grcn_set_weights(g->bottom, &bw, (rgp_stream_t)s));
   rgp_shallownet_weights sw = w->shallownet;
   RGP_TRY(rgp_shallownet_set_weights(g->shallow, &sw, (rgp_stream_t)s));
+  // (packs batched, no memsets of the packed areas: rgp_grcn.hip set_weights_impl)
+  PackBatch<T> pk(ws, s);
   // stride-7 transposed conv phases, filter [11,11,64,256]
   for (ConvDesc& d : g->up) {
-    RGP_HIP(hipMemsetAsync(ws + d.w_off, 0, d.w_bytes(g->dtype), s));
-    RGP_TRY(pack_filter<T>(d, w->upsampling_weight, ws, 64, 0, s));
+    RGP_TRY(pk.add(d, w->upsampling_weight, 64, 0));
   }
   // top cell: filters [5,5,65,3] (x) and [5,5,3,3] (h); gate g, unit n -> packed row g*kSt + n
-  for (ConvDesc* d : {&g->xtop, &g->zr, &g->c, &g->fc1, &g->fc2}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
   g->xtop.cin_src = 65; g->xtop.s_tap = 65LL * 3; g->xtop.s_c = 3; g->xtop.s_n = 1;
-  RGP_TRY(pack_filter<T>(g->xtop, w->top_Wz, ws, 3, 0, s));
-  RGP_TRY(pack_filter<T>(g->xtop, w->top_Wr, ws, 3, kSt, s));
-  RGP_TRY(pack_filter<T>(g->xtop, w->top_W, ws, 3, 2 * kSt, s));
+  RGP_TRY(pk.add(g->xtop, w->top_Wz, 3, 0));
+  RGP_TRY(pk.add(g->xtop, w->top_Wr, 3, kSt));
+  RGP_TRY(pk.add(g->xtop, w->top_W, 3, 2 * kSt));
   for (ConvDesc* d : {&g->zr, &g->c}) { d->cin_src = 3; d->s_tap = 3LL * 3; d->s_c = 3; d->s_n = 1; }
-  RGP_TRY(pack_filter<T>(g->zr, w->top_Uz, ws, 3, 0, s));
-  RGP_TRY(pack_filter<T>(g->zr, w->top_Ur, ws, 3, kSt, s));
-  RGP_TRY(pack_filter<T>(g->c, w->top_U, ws, 3, 0, s));
+  RGP_TRY(pk.add(g->zr, w->top_Uz, 3, 0));
+  RGP_TRY(pk.add(g->zr, w->top_Ur, 3, kSt));
+  RGP_TRY(pk.add(g->c, w->top_U, 3, 0));
   // FCs with interleaved halves (see EpiReluMaxout)
   g->fc1.cin_src = 7203; g->fc2.cin_src = 2401;
   for (ConvDesc* d : {&g->fc1, &g->fc2}) { d->s_tap = 0; d->s_n = 1; d->s_c = 4802; }
-  RGP_TRY(pack_filter<T>(g->fc1, w->fc1_w, ws, 2401, 0, s, 0, 0, 2));
-  RGP_TRY(pack_filter<T>(g->fc1, w->fc1_w + 2401, ws, 2401, 1, s, 0, 0, 2));
-  RGP_TRY(pack_filter<T>(g->fc2, w->fc2_w, ws, 2401, 0, s, 0, 0, 2));
-  RGP_TRY(pack_filter<T>(g->fc2, w->fc2_w + 2401, ws, 2401, 1, s, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc1, w->fc1_w, 2401, 0, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc1, w->fc1_w + 2401, 2401, 1, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc2, w->fc2_w, 2401, 0, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc2, w->fc2_w + 2401, 2401, 1, 0, 0, 2));
+  RGP_TRY(pk.flush());
   interleave2_kernel<<<(2401 + 255) / 256, 256, 0, s>>>(w->fc1_b, (float*)(ws + g->b1i), 2401);
   interleave2_kernel<<<(2401 + 255) / 256, 256, 0, s>>>(w->fc2_b, (float*)(ws + g->b2i), 2401);
   RGP_HIP(hipGetLastError());

@@ -347,16 +347,17 @@ int cascade_bwd_upload(rgp_cascade* g, hipStream_t s) {
 template <typename T>
 static int pack_impl(rgp_cascade* g, const rgp_cascade_weights* w, hipStream_t s) {
   char* ws = g->ws;
-  for (ConvDesc* d : {&g->b_fc2, &g->b_fc1, &g->b_tc, &g->b_tzr, &g->b_tx, &g->b_up}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
-  RGP_TRY(pack_filter<T>(g->b_fc2, w->fc2_w, ws, 2401, 0, s));
-  RGP_TRY(pack_filter<T>(g->b_fc1, w->fc1_w, ws, 7203, 0, s));
-  RGP_TRY(pack_filter<T>(g->b_tc, w->top_U, ws, 3, 0, s));
-  RGP_TRY(pack_filter<T>(g->b_tzr, w->top_Uz, ws, 3, 0, s, 0, 1));
-  RGP_TRY(pack_filter<T>(g->b_tzr, w->top_Ur, ws, 3, 0, s, kSt, 1));
-  RGP_TRY(pack_filter<T>(g->b_tx, w->top_Wz, ws, 64, 0, s, 0, 1));
-  RGP_TRY(pack_filter<T>(g->b_tx, w->top_Wr, ws, 64, 0, s, kSt, 1));
-  RGP_TRY(pack_filter<T>(g->b_tx, w->top_W, ws, 64, 0, s, 2 * kSt, 1));
-  RGP_TRY(pack_filter<T>(g->b_up, w->upsampling_weight, ws, 256, 0, s));
+  PackBatch<T> pk(ws, s);                                   // one launch, no memsets (rgp_grcn.hip set_weights_impl)
+  RGP_TRY(pk.add(g->b_fc2, w->fc2_w, 2401, 0));
+  RGP_TRY(pk.add(g->b_fc1, w->fc1_w, 7203, 0));
+  RGP_TRY(pk.add(g->b_tc, w->top_U, 3, 0));
+  RGP_TRY(pk.add(g->b_tzr, w->top_Uz, 3, 0, 0, 1));
+  RGP_TRY(pk.add(g->b_tzr, w->top_Ur, 3, 0, kSt, 1));
+  RGP_TRY(pk.add(g->b_tx, w->top_Wz, 64, 0, 0, 1));
+  RGP_TRY(pk.add(g->b_tx, w->top_Wr, 64, 0, kSt, 1));
+  RGP_TRY(pk.add(g->b_tx, w->top_W, 64, 0, 2 * kSt, 1));
+  RGP_TRY(pk.add(g->b_up, w->upsampling_weight, 256, 0));
+  RGP_TRY(pk.flush());
   return RGP_OK;
 }
 

@@ -50,26 +50,28 @@ __global__ void interleave_kernel(const float* __restrict__ b, float* __restrict
 template <typename T>
 int set_weights_impl(rgp_shallownet* g, const rgp_shallownet_weights* w, hipStream_t s) {
   char* ws = g->ws;
-  for (ConvDesc* d : {&g->conv1, &g->conv2, &g->conv3, &g->fc1, &g->fc2}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
-  RGP_TRY(pack_filter<T>(g->conv1, w->conv1_w, ws, 32, 0, s));
-  RGP_TRY(pack_filter<T>(g->conv2, w->conv2_w, ws, 64, 0, s));
-  RGP_TRY(pack_filter<T>(g->conv3, w->conv3_w, ws, 32, 0, s));
+  // every pack of this call in one or two launches; no memset of the packed areas (zero from bind time outside the
+  // positions a pack writes, rgp_grcn.hip set_weights_impl)
+  PackBatch<T> pk(ws, s);
+  RGP_TRY(pk.add(g->conv1, w->conv1_w, 32, 0));
+  RGP_TRY(pk.add(g->conv2, w->conv2_w, 64, 0));
+  RGP_TRY(pk.add(g->conv3, w->conv3_w, 32, 0));
   // FC filters [K][4802], halves interleaved: packed row 2j = unit j, 2j+1 = unit j+2401
-  RGP_TRY(pack_filter<T>(g->fc1, w->fc1_w, ws, 2401, 0, s, 0, 0, 2));
-  RGP_TRY(pack_filter<T>(g->fc1, w->fc1_w + 2401, ws, 2401, 1, s, 0, 0, 2));
-  RGP_TRY(pack_filter<T>(g->fc2, w->fc2_w, ws, 2401, 0, s, 0, 0, 2));
-  RGP_TRY(pack_filter<T>(g->fc2, w->fc2_w + 2401, ws, 2401, 1, s, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc1, w->fc1_w, 2401, 0, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc1, w->fc1_w + 2401, 2401, 1, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc2, w->fc2_w, 2401, 0, 0, 0, 2));
+  RGP_TRY(pk.add(g->fc2, w->fc2_w + 2401, 2401, 1, 0, 0, 2));
   interleave_kernel<<<(2401 + 255) / 256, 256, 0, s>>>(w->fc1_b, (float*)(ws + g->b1i), 2401);
   interleave_kernel<<<(2401 + 255) / 256, 256, 0, s>>>(w->fc2_b, (float*)(ws + g->b2i), 2401);
   RGP_HIP(hipGetLastError());
   g->b_conv1 = w->conv1_b; g->b_conv2 = w->conv2_b; g->b_conv3 = w->conv3_b;
   if (g->save) {
-    for (ConvDesc* d : {&g->b_fc2, &g->b_fc1, &g->b_c3, &g->b_c2}) RGP_HIP(hipMemsetAsync(ws + d->w_off, 0, d->w_bytes(g->dtype), s));
-    RGP_TRY(pack_filter<T>(g->b_fc2, w->fc2_w, ws, 2401, 0, s));
-    RGP_TRY(pack_filter<T>(g->b_fc1, w->fc1_w, ws, g->nflat, 0, s));
-    RGP_TRY(pack_filter<T>(g->b_c3, w->conv3_w, ws, 64, 0, s));
-    RGP_TRY(pack_filter<T>(g->b_c2, w->conv2_w, ws, 32, 0, s));
+    RGP_TRY(pk.add(g->b_fc2, w->fc2_w, 2401, 0));
+    RGP_TRY(pk.add(g->b_fc1, w->fc1_w, g->nflat, 0));
+    RGP_TRY(pk.add(g->b_c3, w->conv3_w, 64, 0));
+    RGP_TRY(pk.add(g->b_c2, w->conv2_w, 32, 0));
   }
+  RGP_TRY(pk.flush());
   g->weights_set = true;
   return RGP_OK;
 }
