@@ -34,6 +34,7 @@ extern "C" {
 #define RGP_EHIP (-2)     /* a HIP runtime call failed */
 #define RGP_EWORKSPACE (-3) /* workspace missing or too small */
 #define RGP_ESTATE (-4)   /* call order violated (e.g. forward before set_weights) */
+#define RGP_ETIMEOUT (-5) /* a persistent ConvGRU launch lost a group member: its outputs are NaN-poisoned (rgp_grcn_status) */
 
 #define RGP_F32 0
 #define RGP_BF16 1
@@ -65,7 +66,27 @@ typedef struct rgp_grcn_weights {
 /* Plan for GazePredictionGRCN.create_gazeprediction_network (gaze_grcn.py:173-376)
  * at fixed batch B, timesteps T, dim_cnn_proj P (512), rnn_state_size S (128). */
 int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int dim_state, int dtype,
-                    int save_for_backward);
+                    int flags);
+/* flags (0 / 1 keep the meaning of the former `save_for_backward` argument):
+ *  RGP_GRCN_SAVE_FOR_BACKWARD  training plan (gates, states and operand images kept for rgp_grcn_backward);
+ *  RGP_GRCN_PER_STEP           run the ConvGRU recurrence and its BPTT as per-timestep launches even where the
+ *                              persistent kernels apply (bf16, 128 state channels, <= 64 clips): the library's second
+ *                              implementation of the recurrence, always used by f32 plans. */
+#define RGP_GRCN_SAVE_FOR_BACKWARD 1
+#define RGP_GRCN_PER_STEP 2
+/* The persistent ConvGRU kernels (one launch for all T steps, forward and BPTT) need all their workgroups resident
+ * together: keep ONE of them in flight per device.  Launches issued through this library from one process are
+ * serialised against each other automatically (any stream, any plan); a launch that nevertheless loses a group member
+ * -- another process running the same kernels on the device -- gives up after about a second, NaN-poisons everything
+ * computed from it (logits, maps, states, gradients) and raises the plan's error state: the next call on the plan
+ * returns RGP_ETIMEOUT, and so does rgp_grcn_status, which first waits for `stream`.  The state is cleared by being
+ * reported. */
+int rgp_grcn_status(rgp_grcn_t* plan, rgp_stream_t stream);
+/* Test hook: the next persistent sequence (kind 1) / BPTT (kind 2) launch of the plan runs without one member of its
+ * first group, i.e. exercises the time-out path above (about one second).  RGP_ESTATE if the plan uses per-step launches. */
+#define RGP_FAULT_SEQ_LOST_MEMBER 1
+#define RGP_FAULT_BPTT_LOST_MEMBER 2
+int rgp_grcn_inject_fault(rgp_grcn_t* plan, int kind);
 int rgp_grcn_destroy(rgp_grcn_t* plan);
 size_t rgp_grcn_workspace_bytes(const rgp_grcn_t* plan);
 /* Uploads the offset tables and zeroes the halos.  Once per workspace. */
@@ -341,7 +362,21 @@ size_t rgp_c3d_layer_elems(const rgp_c3d_t* plan, int layer, int n_windows);
  * [n*49,1024] fp32 (layout of `rows`), exactly one non-NULL -- and ACCUMULATES (+=) the parameter
  * gradients into grads, a flat fp32 vector laid out w[0] (DHWIO), b[0], w[1], b[1], ... (the caller zeroes
  * it; rgp_c3d_param_offset gives each piece's element offset, rgp_c3d_param_elems the total). */
-int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for_backward);
+int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int flags);
+/* flags of rgp_c3d_create_ex (0 / 1 keep the meaning of the former `save_for_backward` argument):
+ *  RGP_C3D_SAVE_FOR_BACKWARD  training plan (arg-max codes, gradient images).
+ *  RGP_C3D_KERNELS_IGEMM      bf16 plans: conv2a..conv4b (forward and input gradients) run through the general
+ *                             implicit-GEMM kernels and their filter gradients through the general filter-gradient
+ *                             kernel instead of the layer-specific patch kernels -- the library's second, independent
+ *                             implementation of those layers (tile chosen by problem size: 256x256 / 512x128 /
+ *                             staggered 256x128 / 128x128), kept for cross-checking the default path.
+ *  RGP_C3D_KERNELS_TILE128    with RGP_C3D_KERNELS_IGEMM: every implicit GEMM of the plan on the 128x128 tile loop. */
+#define RGP_C3D_SAVE_FOR_BACKWARD 1
+#define RGP_C3D_KERNELS_IGEMM 2
+#define RGP_C3D_KERNELS_TILE128 4
+/* Name of the kernel instantiation the plan launches for layer i's forward at n_windows windows ("" if unknown):
+ * what a profiler shows for the stage rgp_c3d_profile_read times as index i. */
+const char* rgp_c3d_layer_kernel_name(const rgp_c3d_t* plan, int layer, int n_windows);
 size_t rgp_c3d_param_elems(const rgp_c3d_t* plan);
 size_t rgp_c3d_param_offset(const rgp_c3d_t* plan, int layer, int is_bias);
 int rgp_c3d_backward(rgp_c3d_t* plan, const float* d_features, const float* d_rows, int n_windows, float* grads,

@@ -16,6 +16,10 @@ import torch  # noqa: F401
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librgp_hip.so')
 
 RGP_F32, RGP_BF16 = 0, 1
+RGP_ETIMEOUT = -5
+RGP_GRCN_SAVE_FOR_BACKWARD, RGP_GRCN_PER_STEP = 1, 2
+RGP_C3D_SAVE_FOR_BACKWARD, RGP_C3D_KERNELS_IGEMM, RGP_C3D_KERNELS_TILE128 = 1, 2, 4
+RGP_FAULT_SEQ_LOST_MEMBER, RGP_FAULT_BPTT_LOST_MEMBER = 1, 2
 RGP_SQNORM_PARTIALS = 256          # include/rgp.h
 DTYPES = {'f32': RGP_F32, 'fp32': RGP_F32, 'float32': RGP_F32, 'bf16': RGP_BF16, 'bfloat16': RGP_BF16}
 
@@ -61,6 +65,9 @@ SIGNATURES = {
     'rgp_device_arch': (c_int, [c_char_p, c_int]),
     'rgp_grcn_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
     'rgp_grcn_destroy': (c_int, [c_void_p]),
+    'rgp_grcn_status': (c_int, [c_void_p, c_void_p]),
+    'rgp_grcn_inject_fault': (c_int, [c_void_p, c_int]),
+    'rgp_c3d_layer_kernel_name': (c_char_p, [c_void_p, c_int, c_int]),
     'rgp_grcn_workspace_bytes': (c_size_t, [c_void_p]),
     'rgp_grcn_bind_workspace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'rgp_grcn_set_weights': (c_int, [c_void_p, ctypes.POINTER(GrcnWeights), c_void_p]),

@@ -31,7 +31,9 @@ struct BpttParams {
   bf16_t* xch_z;
   bf16_t* xch_r;
   unsigned* cnt;             // [ngroups][2T] phase counters, zeroed before the launch
+  unsigned* err;             // host-visible error word of the plan (convgru_seq.hip.h)
   int B, T, NC, ngroups;
+  int skip_member;           // fault injection: this member of group 0 leaves at once; -1 = none
 };
 
 template <int NF>
@@ -50,6 +52,7 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
     if ((p.ngroups & 7) == 0) { const int slot = b >> 3; group = (slot >> 3) * 8 + (b & 7); j = slot & 7; }
     else { group = b >> 3; j = b & 7; }
   }
+  if (group == 0 && j == p.skip_member) return;           // fault injection: a member that never arrives
   const int clip0 = group * p.NC;
   const int nclip = min(p.NC, p.B - clip0);
   const int rows = nclip * 49;
@@ -274,6 +277,7 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
   }
   // a group that timed out must not look like a result
   if (s_timeout) {
+    if (tid == 0 && p.err) { *(volatile unsigned*)p.err = 1u; __threadfence_system(); }
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll

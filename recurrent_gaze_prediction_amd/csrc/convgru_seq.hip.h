@@ -43,7 +43,9 @@ struct SeqParams {
   bf16_t* xch_h;             // [ngroups][98][128] exchange image of h'
   bf16_t* xch_rh;            // [ngroups][98][128] exchange image of r.h
   unsigned* cnt;             // [ngroups][2T] phase counters, zeroed before the launch
+  unsigned* err;             // host-visible error word of the plan (pinned, mapped): set to 1 by a group that timed out
   int B, T, NC, ngroups, K;
+  int skip_member;           // fault injection (rgp_grcn_inject_fault): this member of group 0 leaves at once; -1 = none
 };
 
 constexpr int SEQ_PIXB = 272;                        // bytes per padded pixel: 128 ch bf16 + 16 pad (bank rotation)
@@ -85,6 +87,7 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
     if ((p.ngroups & 7) == 0) { const int slot = b >> 3; group = (slot >> 3) * 8 + (b & 7); j = slot & 7; }
     else { group = b >> 3; j = b & 7; }
   }
+  if (group == 0 && j == p.skip_member) return;           // fault injection: a member that never arrives
   const int clip0 = group * p.NC;
   const int nclip = min(p.NC, p.B - clip0);
   const int rows = nclip * 49;
@@ -334,13 +337,23 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
           p.hbn[(fr * 81 + (r49 / 7 + 1) * 9 + (r49 % 7 + 1)) * S + ch] = f2bf(gam * (hn[o][r] * p.bn_inv_std) + bet);
         }
   }
-  // a group that timed out must not look like a result
+  // a group that timed out must not look like a result: the head reads hbn (every frame of the group's clips: the
+  // exchange images were stale from the first missed phase on), the training path hall
   if (s_timeout) {
+    if (tid == 0 && p.err) { *(volatile unsigned*)p.err = 1u; __threadfence_system(); }
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (ovalid[o][r]) p.hall[(long long)T_ * st + ((long long)(clip0 * 49 + orow[o][r])) * S + ch] = __builtin_nanf("");
+        if (ovalid[o][r]) {
+          const int c = orow[o][r] / 49, r49 = orow[o][r] - c * 49;
+          const long long off = ((long long)(clip0 * 49 + orow[o][r])) * S + ch;
+          for (int t = 0; t < T_; ++t) {
+            const long long fr = (long long)(clip0 + c) * T_ + t;
+            p.hbn[(fr * 81 + (r49 / 7 + 1) * 9 + (r49 % 7 + 1)) * S + ch] = (bf16_t)0x7FC0;     // bf16 NaN
+            p.hall[(long long)(t + 1) * st + off] = __builtin_nanf("");
+          }
+        }
   }
 }
 

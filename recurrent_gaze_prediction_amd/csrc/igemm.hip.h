@@ -69,6 +69,7 @@ struct IgemmParams {
   int nk;                    // K / BKE
   int ntile_group = 0;       // staggered kernel: row tiles per column-tile run (0 / 1 = column tiles innermost)
   int pool_regs = 1;         // staggered kernel, P = 8 without arg-max: pool in registers before staging (RGP_POOLREGS)
+  int tile128 = 0;           // host side only (launch_igemm): 1 = never the 256-row persistent kernels (RGP_C3D_KERNELS_TILE128)
 };
 
 // Epilogue operands (superset; each functor reads what it needs).

@@ -14,6 +14,7 @@ namespace {
 template <typename T, int G, int P>
 int run_layer(rgp_c3d* c, int i, int n, hipStream_t s) {
   IgemmParams p = make_params(c->L[i], c->ws + c->act_off[i], c->ws, n);
+  p.tile128 = c->tile128();
   EpiParams e = make_epi(c->L[i], c->ws + c->act_off[i + 1], c->ws);
   e.bias = c->bias[i];
   if (c->save && P > 1) e.argmax = (unsigned char*)(c->ws + c->B[i].argmax_off);
@@ -48,7 +49,7 @@ int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   constexpr int G0 = sizeof(T) == 2 ? 4 : 2;
   if (i == 0 && sizeof(T) == 2) return run_conv1a_bf16(c, n, s);
   // conv2a ... conv4b: the patch kernels (conv_patch.hip.h, conv_patch14.hip.h); they read the filter in its chunk-major packing
-  if (sizeof(T) == 2 && ((i == 1 && dev_knob("RGP_C2PATCH", 1)) || (i == 3 && c->L[3].chunk_major == 64 && dev_knob("RGP_C3PATCH", 1)) ||
+  if (sizeof(T) == 2 && c->use_patch() && ((i == 1 && dev_knob("RGP_C2PATCH", 1)) || (i == 3 && c->L[3].chunk_major == 64 && dev_knob("RGP_C3PATCH", 1)) ||
                                      (i == 2 && c->L[2].chunk_major == 64 && dev_knob("RGP_C3APATCH", 1)) ||
                                      ((i == 4 || i == 5) && c->L[i].chunk_major == 64 && dev_knob("RGP_C4PATCH", 1))))
     return run_conv_patch_bf16(c, i, n, s);
@@ -115,14 +116,18 @@ extern "C" {
 
 int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) { return rgp_c3d_create_ex(plan, max_windows, dtype, 0); }
 
-int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int save_for_backward) {
+int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int flags) {
   RGP_REQUIRE(plan && max_windows > 0, "rgp_c3d_create: bad arguments");
+  RGP_REQUIRE((flags & ~(RGP_C3D_SAVE_FOR_BACKWARD | RGP_C3D_KERNELS_IGEMM | RGP_C3D_KERNELS_TILE128)) == 0, "rgp_c3d_create_ex: unknown flags 0x%x", flags);
+  RGP_REQUIRE(!(flags & RGP_C3D_KERNELS_TILE128) || (flags & RGP_C3D_KERNELS_IGEMM), "rgp_c3d_create_ex: RGP_C3D_KERNELS_TILE128 needs RGP_C3D_KERNELS_IGEMM");
+  const int save_for_backward = flags & RGP_C3D_SAVE_FOR_BACKWARD;
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_c3d_create: dtype %d", dtype);
   RGP_REQUIRE((long long)max_windows * 16 * 112 * 112 < (1LL << 31), "rgp_c3d_create: max_windows too large");
   rgp_c3d* c = new rgp_c3d();
   c->max_windows = max_windows;
   c->dtype = dtype;
   c->save = save_for_backward != 0;
+  c->kernels = flags & (RGP_C3D_KERNELS_IGEMM | RGP_C3D_KERNELS_TILE128);
   bool ok = true;
   Arena a;
   for (int i = 0; i < 8; ++i) {
@@ -298,6 +303,33 @@ int rgp_c3d_frames_to_video(rgp_c3d_t* c, const unsigned char* frames, int n_fra
     RGP_HIP(hipGetLastError());
   }
   return RGP_OK;
+}
+
+const char* rgp_c3d_layer_kernel_name(const rgp_c3d_t* c, int i, int n_windows) {
+  static thread_local char buf[96];
+  buf[0] = 0;
+  if (!c || i < 0 || i > 7 || n_windows <= 0) return buf;
+  const int n = std::min(n_windows, c->max_windows);
+  const C3dLayerSpec& l = kLayers[i];
+  const int P = l.pd * l.ph * l.ph;
+  const bool bf = c->dtype == RGP_BF16;
+  if (bf && i == 0) {
+    snprintf(buf, sizeof(buf), "conv1a_pool_bf16_kernel<%s>", c->save ? "act0,argmax" : "fused");
+  } else if (bf && c->use_patch() && i >= 1 && i <= 3 && (i == 1 || c->L[i].chunk_major == 64)) {
+    snprintf(buf, sizeof(buf), "conv_patch_bf16_kernel<%d,%d,%d,%d,pool%d>", l.cin, l.cout, l.H, l.D, P);
+  } else if (bf && c->use_patch() && (i == 4 || i == 5) && c->L[i].chunk_major == 64) {
+    snprintf(buf, sizeof(buf), "conv_patch14_bf16_kernel<%d,pool%d>", l.cin, P);
+  } else {
+    IgemmParams p = make_params(c->L[i], c->ws, c->ws, n);
+    p.tile128 = c->tile128();
+    IgemmTile t;
+    using EB = EpiStore<bf16_t, true, true>;
+    using EF = EpiStore<float, true, true>;
+    if (bf) t = P == 8 ? igemm_tile_choice<bf16_t, 1, 8, EB>(p, 1) : P == 4 ? igemm_tile_choice<bf16_t, 4, 4, EB>(p, 1) : igemm_tile_choice<bf16_t, 1, 1, EB>(p, 1);
+    else t = P == 8 ? igemm_tile_choice<float, 1, 8, EF>(p, 1) : P == 4 ? igemm_tile_choice<float, 2, 4, EF>(p, 1) : igemm_tile_choice<float, 1, 1, EF>(p, 1);
+    snprintf(buf, sizeof(buf), "%s,%s,pool%d>", igemm_tile_name(t), bf ? "bf16" : "f32", P);
+  }
+  return buf;
 }
 
 int rgp_c3d_profile_enable(rgp_c3d_t* c, int enable) {

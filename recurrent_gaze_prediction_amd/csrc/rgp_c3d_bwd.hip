@@ -205,7 +205,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         RGP_TRY((launch_wgrad<T, G0>(p, s)));
         conv1a_unpack_grad_kernel<<<(27 * 3 * 64 + 255) / 256, 256, 0, s>>>(p.dW, grads + b.grad_w);
         RGP_HIP(hipGetLastError());
-      } else if (sizeof(T) == 2 && i >= 1 && i <= 3 && ((dev_knob("RGP_WGPATCH", 7) >> (i - 1)) & 1)) {
+      } else if (sizeof(T) == 2 && c->use_patch() && i >= 1 && i <= 3 && ((dev_knob("RGP_WGPATCH", 7) >> (i - 1)) & 1)) {
         // wgrad_patch.hip.h: conv2a 5.2 -> 4.0 ms, conv3a 2.3 -> 2.3, conv3b 4.8 -> 4.3 ms per 256 windows against
         // wgrad_kernel (dev builds: one mask bit per layer)
         RGP_TRY(run_wgrad_patch(c, i, n, grads + b.grad_w, s));
@@ -220,8 +220,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     // gradient w.r.t. the layer input = pooled (or plain) output of layer i-1
     const C3dBwdLayer& lo = c->B[i - 1];
     IgemmParams p = make_params(b.dg, ws + b.dypre_off, ws, n);
+    p.tile128 = c->tile128();
     if (pooled(i - 1)) {
-      if (sizeof(T) == 2 && (i == 1 || i == 2) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+      if (sizeof(T) == 2 && c->use_patch() && (i == 1 || i == 2) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
         RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));      // conv_patch.hip.h, dense output
       } else {
         EpiParams e = make_epi(b.dg, ws + c->dyp_off, ws);
@@ -237,7 +238,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
           (const int*)(ws + c->unpad_off[i - 1]), c->act_stride[i], (T*)(ws + lo.dypre_off), (const int*)(ws + lo.win_tab_off),
           (const int*)(ws + lo.q_off_off), lo.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, rows, grads + lo.grad_b);
       RGP_HIP(hipGetLastError());
-    } else if (sizeof(T) == 2 && (i == 3 || i == 5) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+    } else if (sizeof(T) == 2 && c->use_patch() && (i == 3 || i == 5) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
       RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));        // conv_patch.hip.h / conv_patch14.hip.h
     } else {
       EpiParams e = make_epi(b.dg, ws + lo.dypre_off, ws);

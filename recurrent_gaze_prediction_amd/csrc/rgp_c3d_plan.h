@@ -29,6 +29,9 @@ struct C3dBwdLayer {
 
 struct rgp_c3d {
   int max_windows = 0, dtype = RGP_BF16;
+  int kernels = 0;               // 0: patch kernels for conv2a..conv4b (bf16); RGP_C3D_KERNELS_IGEMM / _TILE128 bits otherwise
+  bool use_patch() const { return dtype == RGP_BF16 && !(kernels & RGP_C3D_KERNELS_IGEMM); }
+  bool tile128() const { return (kernels & RGP_C3D_KERNELS_TILE128) != 0; }
   rgp::ConvDesc L[8];
   size_t act_off[9] = {0};       // act[i] = halo-padded input of layer i; act[8] = conv5b rows
   long long act_stride[9] = {0}; // elements per window

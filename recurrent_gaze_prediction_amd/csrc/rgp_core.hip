@@ -39,6 +39,41 @@ int device_cu_count(int* n_cu) {
   return RGP_OK;
 }
 
+namespace {
+struct PersistentGuard {
+  std::mutex mu;
+  hipEvent_t ev[64] = {nullptr};
+  bool recorded[64] = {false};
+};
+PersistentGuard g_guard;
+bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+}  // namespace
+
+int persistent_guard_begin(hipStream_t s) {
+  if (stream_capturing(s)) return RGP_OK;
+  int dev = 0;
+  RGP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return RGP_OK;
+  std::lock_guard<std::mutex> lock(g_guard.mu);
+  if (g_guard.recorded[dev]) RGP_HIP(hipStreamWaitEvent(s, g_guard.ev[dev], 0));
+  return RGP_OK;
+}
+
+int persistent_guard_end(hipStream_t s) {
+  if (stream_capturing(s)) return RGP_OK;
+  int dev = 0;
+  RGP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return RGP_OK;
+  std::lock_guard<std::mutex> lock(g_guard.mu);
+  if (!g_guard.ev[dev]) RGP_HIP(hipEventCreateWithFlags(&g_guard.ev[dev], hipEventDisableTiming));
+  RGP_HIP(hipEventRecord(g_guard.ev[dev], s));
+  g_guard.recorded[dev] = true;
+  return RGP_OK;
+}
+
 thread_local char g_err[512] = "";
 
 namespace {

@@ -136,7 +136,11 @@ int seq_persistent(rgp_grcn* g, hipStream_t s) {
   p.xch_rh = (bf16_t*)(g->ws + g->xch_rh.off);
   p.cnt = (unsigned*)(g->ws + g->seq_cnt.off);
   p.B = B; p.T = T_; p.NC = g->seq_nc; p.ngroups = g->seq_groups; p.K = g->gzr.K;
+  p.err = g->err_host;
+  p.skip_member = (g->fault & 1) ? 7 : -1;
+  g->fault &= ~1;
   RGP_REQUIRE(g->gzr.K == 9 * S && g->gc.K == 9 * S && g->gzr.chunk_major == 0, "convgru_seq: unexpected filter packing");
+  RGP_TRY(persistent_guard_begin(s));
   if (g->seq_nc == 1) {
     RGP_TRY(ensure_dyn_smem((const void*)convgru_seq_kernel<4>, SEQ_SMEM));
     convgru_seq_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
@@ -145,7 +149,7 @@ int seq_persistent(rgp_grcn* g, hipStream_t s) {
     convgru_seq_kernel<7><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
   }
   RGP_HIP(hipGetLastError());
-  return RGP_OK;
+  return persistent_guard_end(s);
 }
 
 template <typename T>
@@ -247,20 +251,31 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   return RGP_OK;
 }
 
-int check_ready(const rgp_grcn* g) {
+int check_ready(rgp_grcn* g) {
   if (!g) return set_err(RGP_EINVAL, "null plan");
   if (!g->ws) return set_err(RGP_EWORKSPACE, "rgp_grcn: workspace not bound");
   if (!g->weights_set) return set_err(RGP_ESTATE, "rgp_grcn: weights not set");
-  return RGP_OK;
+  return grcn_check_error(g);
 }
 
 }  // namespace
 
+int grcn_check_error(rgp_grcn* g) {
+  if (g->err_host && *(volatile unsigned*)g->err_host) {
+    *(volatile unsigned*)g->err_host = 0u;
+    return set_err(RGP_ETIMEOUT, "rgp_grcn: a persistent ConvGRU launch of this plan lost a group member (another launch was "
+                   "resident on the device?): its outputs were NaN-poisoned");
+  }
+  return RGP_OK;
+}
+
 extern "C" {
 
 int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int dim_state, int dtype,
-                    int save_for_backward) {
+                    int flags) {
   RGP_REQUIRE(plan, "rgp_grcn_create: null out pointer");
+  RGP_REQUIRE((flags & ~(RGP_GRCN_SAVE_FOR_BACKWARD | RGP_GRCN_PER_STEP)) == 0, "rgp_grcn_create: unknown flags 0x%x", flags);
+  const int save_for_backward = flags & RGP_GRCN_SAVE_FOR_BACKWARD;
   RGP_REQUIRE(batch > 0 && n_steps > 0, "rgp_grcn_create: batch=%d n_steps=%d", batch, n_steps);
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_grcn_create: dtype %d", dtype);
   const int Bk = bke(dtype);
@@ -360,7 +375,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->frame_loss = take(a, (size_t)F * 4);
   // persistent sequence kernel (convgru_seq.hip.h): the reference cell (128 state channels on 7x7), bf16 operands,
   // up to 2 clips per group of 8 workgroups and at most 32 groups (= the 256 CUs)
-  if (dtype == RGP_BF16 && S == 128 && batch <= 64) {
+  if (dtype == RGP_BF16 && S == 128 && batch <= 64 && !(flags & RGP_GRCN_PER_STEP)) {
     g->seq_nc = (batch + 31) / 32;
     g->seq_groups = (batch + g->seq_nc - 1) / g->seq_nc;
     g->xch_h = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
@@ -378,7 +393,21 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
 
 int rgp_grcn_destroy(rgp_grcn_t* plan) {
   if (plan) grcn_bwd_destroy(plan);
+  if (plan && plan->err_host) (void)hipHostFree(plan->err_host);
   delete plan;
+  return RGP_OK;
+}
+
+int rgp_grcn_status(rgp_grcn_t* g, rgp_stream_t stream) {
+  RGP_REQUIRE(g, "rgp_grcn_status: null plan");
+  RGP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return grcn_check_error(g);
+}
+
+int rgp_grcn_inject_fault(rgp_grcn_t* g, int kind) {
+  RGP_REQUIRE(g && (kind == RGP_FAULT_SEQ_LOST_MEMBER || kind == RGP_FAULT_BPTT_LOST_MEMBER), "rgp_grcn_inject_fault: bad arguments");
+  if (!seq_persistent_ok(g)) return set_err(RGP_ESTATE, "rgp_grcn_inject_fault: the plan does not use the persistent ConvGRU kernels");
+  g->fault |= kind;
   return RGP_OK;
 }
 
@@ -389,6 +418,14 @@ int rgp_grcn_bind_workspace(rgp_grcn_t* g, void* workspace, size_t bytes, rgp_st
   if (bytes < g->ws_bytes) return set_err(RGP_EWORKSPACE, "workspace %zu < required %zu bytes", bytes, g->ws_bytes);
   RGP_REQUIRE(((size_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (g->seq_groups > 0 && !g->err_host) {
+    // error word of the persistent kernels: pinned host memory the device writes directly, so the host can test it at
+    // the start of any later call without a synchronisation (host memory, not device memory: header conventions)
+    void* e = nullptr;
+    RGP_HIP(hipHostMalloc(&e, 64, hipHostMallocMapped));
+    g->err_host = (unsigned*)e;
+    *(volatile unsigned*)g->err_host = 0u;
+  }
   g->ws = (char*)workspace;
   g->weights_set = false;
   // zero everything once: halos of E / Hp / RHp / Hbn / D1 / D2 stay zero because

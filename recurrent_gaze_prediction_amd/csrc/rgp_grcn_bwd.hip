@@ -206,7 +206,11 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     q.xch_c = (bf16_t*)(ws + b->xch_c.off); q.xch_z = (bf16_t*)(ws + b->xch_z.off); q.xch_r = (bf16_t*)(ws + b->xch_r.off);
     q.cnt = (unsigned*)(ws + b->bptt_cnt.off);
     q.B = B; q.T = T_; q.NC = g->seq_nc; q.ngroups = g->seq_groups;
+    q.err = g->err_host;
+    q.skip_member = (g->fault & 2) ? 7 : -1;
+    g->fault &= ~2;
     RGP_REQUIRE(b->b_c.K == 9 * S && b->b_zr.K == 18 * S, "convgru_bptt: unexpected filter packing");
+    RGP_TRY(persistent_guard_begin(s));
     if (g->seq_nc == 1) {
       RGP_TRY(ensure_dyn_smem((const void*)convgru_bptt_kernel<4>, SEQ_SMEM));
       convgru_bptt_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(q);
@@ -215,6 +219,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       convgru_bptt_kernel<7><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(q);
     }
     RGP_HIP(hipGetLastError());
+    RGP_TRY(persistent_guard_end(s));
   }
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
@@ -452,6 +457,7 @@ int rgp_grcn_backward(rgp_grcn_t* g, const float* logits, const float* probs, co
   if (!g->ws) return set_err(RGP_EWORKSPACE, "rgp_grcn: workspace not bound");
   if (!g->save || !g->bwd) return set_err(RGP_ESTATE, "rgp_grcn_backward: plan was created without save_for_backward");
   if (!g->weights_set) return set_err(RGP_ESTATE, "rgp_grcn: weights not set");
+  RGP_TRY(grcn_check_error(g));
   RGP_REQUIRE(loss_type == 0 || loss_type == 1, "rgp_grcn_backward: loss_type %d (0 xentropy, 1 l2)", loss_type);
   RGP_REQUIRE(loss_type == 1 || probs, "rgp_grcn_backward: xentropy needs the softmax maps");
   const float* const* ptrs = (const float* const*)grads;

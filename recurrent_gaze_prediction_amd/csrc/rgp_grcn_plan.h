@@ -18,6 +18,8 @@ struct rgp_grcn {
   Buf xt, E, xpre, hall, uall, rall, call, hp, rhp, hbn, D1, D2, gfold, frame_loss, gtoep, bias16;
   Buf xch_h, xch_rh, seq_cnt;   // persistent ConvGRU sequence kernel: exchange images [groups][98][128] + phase counters
   int seq_nc = 0, seq_groups = 0;   // clips per group / groups (0 = the per-step path)
+  unsigned* err_host = nullptr;     // pinned, device-visible error word: a persistent launch that timed out sets it
+  int fault = 0;                    // rgp_grcn_inject_fault: bit 0 next sequence launch, bit 1 next BPTT launch lose a member
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool weights_set = false;
@@ -37,6 +39,8 @@ inline Buf take(rgp::Arena& a, size_t bytes) {
 // rgp_grcn.hip: the persistent ConvGRU kernels apply to this plan on the current device
 bool seq_persistent_ok(const rgp_grcn* g);
 // rgp_grcn_bwd.hip
+// returns RGP_ETIMEOUT (and clears the word) if a persistent launch of this plan reported a lost group member
+int grcn_check_error(rgp_grcn* g);
 int grcn_bwd_plan(rgp_grcn* g, rgp::Arena& a);
 int grcn_bwd_upload(rgp_grcn* g, hipStream_t s);
 int grcn_bwd_pack(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s);

@@ -53,6 +53,15 @@ constexpr int dev_knob(const char*, int dflt) { return dflt; }
 int ensure_dyn_smem(const void* kernel, int bytes);
 int device_cu_count(int* n_cu);
 
+// The persistent ConvGRU kernels (convgru_seq.hip.h, convgru_bptt.hip.h) need every workgroup of a launch resident at
+// once: two such launches must never share the device.  Within one process that is enforced here: a launch on stream s
+// is bracketed by persistent_guard_begin / _end, which make s wait for the previous persistent launch of the process on
+// the current device (whatever stream or plan issued it) and record this one.  Skipped while s is being captured (a
+// graph replays on one stream).  Other processes on the same device are outside its reach: the kernels' own time-out
+// (RGP_ETIMEOUT) is what reports those.
+int persistent_guard_begin(hipStream_t s);
+int persistent_guard_end(hipStream_t s);
+
 // Row tables of the filter-gradient kernel (wgrad.hip.h): byte offset of row m = (z*H + y)*W + x of a D x H x W grid
 // from its image in X (z*x_sz + y*x_sy + x*x_sx elements) and in dY (y_org + z*y_sz + y*y_sy + x*y_sx), entries
 // [0, D*H*W + 32), entry e >= D*H*W continuing into the following image(s).  Built on the device the first time a
@@ -264,37 +273,72 @@ int launch_wide(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
   return RGP_OK;
 }
 
-// Tile choice by output width: 128x128 (2x2 waves of 64x64) for N >= 128,
-// 128x64 (2x2 waves of 64x32) for N in (32, 64], 128x32 (4x1 waves of 32x32) below.
+// Tile choice by problem size and output width.  The persistent 256-row kernels (igemm_wide.hip.h, igemm_stagger.hip.h)
+// need about a thousand tiles; below that 128x128 (2x2 waves of 64x64) for N >= 128, 128x64 (2x2 waves of 64x32) for N
+// in (32, 64], 128x32 (4x1 waves of 32x32) below, and 64x64 for the latency-bound recurrent convs.
+enum IgemmTile { TILE_WIDE_256x256, TILE_WIDE_512x128, TILE_STAGGER_256x128, TILE_LOOP_256x128, TILE_64x64, TILE_128x128, TILE_128x64, TILE_128x32 };
+
 template <typename T, int G, int P, class Epi>
-int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
-  if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
-  // 2 = staggered 256x128 kernel where eligible (default, fastest measured), 0 = 128x128 only,
+IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
+  // dev builds -- 2 = staggered 256x128 kernel where eligible (default, fastest measured), 0 = 128x128 only,
   // 1 = 256x128 simple loop (dev comparison)
-  const int tile_cfg = dev_knob("RGP_TILE", 2);
+  const int tile_cfg = p.tile128 ? 0 : dev_knob("RGP_TILE", 2);
   // N >= 256 bf16 convolutions at C3D scale: the 256x256 tile (two thirds of the L2 -> LDS bytes per FLOP)
   if constexpr (sizeof(T) == 2 && G == 1 && (P == 1 || P == 8) && EpiWideOk<Epi>::value) {
     // (at least four tiles per CU: with fewer -- conv5a/b at 1024 windows: 784 -- the last, partly filled round of the
     // persistent walk costs more than the bytes saved, and the 256x128 kernel's 1568 tiles run faster)
-    const int wide = dev_knob("RGP_WIDE", 3);
+    const int wide = p.tile128 ? 0 : dev_knob("RGP_WIDE", 3);
     if (ksplit == 1 && p.nk >= 2 && p.nk <= 256) {
-      if ((wide & 1) && p.N % 256 == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 1024) {
-#ifdef RGP_DEV_KNOBS
-        if (dev_knob("RGP_WVAR", 0) == 1) return launch_wide<256, 256, P, Epi, 1>(p, e, s);
-#endif
-        return launch_wide<256, 256, P, Epi>(p, e, s);
-      }
-      if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024) {
-#ifdef RGP_DEV_KNOBS
-        if (dev_knob("RGP_WVAR", 0) == 2) return launch_wide<512, 128, P, Epi, 2>(p, e, s);
-        if (dev_knob("RGP_WVAR", 0) == 3) return launch_wide<512, 128, P, Epi, 1>(p, e, s);
-#endif
-        return launch_wide<512, 128, P, Epi>(p, e, s);
-      }
+      if ((wide & 1) && p.N % 256 == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 1024) return TILE_WIDE_256x256;
+      if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024) return TILE_WIDE_512x128;
     }
   }
-  if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256)
+  if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256) return TILE_STAGGER_256x128;
+  if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return TILE_LOOP_256x128;
+  // latency-bound problems (the per-timestep recurrent convs: M = B*49): 64x64 tiles give 4x the
+  // blocks of 128x128, so more of the 256 CUs have a tile
   {
+    const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (ksplit == 1 && p.N >= 64 && tiles128 * ksplit < 160) return TILE_64x64;
+  }
+  if (p.N > 64) return TILE_128x128;
+  if (p.N > 32) return TILE_128x64;
+  return TILE_128x32;
+}
+
+inline const char* igemm_tile_name(IgemmTile t) {
+  switch (t) {
+    case TILE_WIDE_256x256: return "igemm_wide_kernel<256x256";
+    case TILE_WIDE_512x128: return "igemm_wide_kernel<512x128";
+    case TILE_STAGGER_256x128: return "igemm_stagger_kernel<256x128";
+    case TILE_LOOP_256x128: return "igemm_kernel<256x128";
+    case TILE_64x64: return "igemm_kernel<64x64";
+    case TILE_128x128: return "igemm_kernel<128x128";
+    case TILE_128x64: return "igemm_kernel<128x64";
+    default: return "igemm_kernel<128x32";
+  }
+}
+
+template <typename T, int G, int P, class Epi>
+int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
+  if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
+  const IgemmTile tile = igemm_tile_choice<T, G, P, Epi>(p, ksplit);
+  if constexpr (sizeof(T) == 2 && G == 1 && (P == 1 || P == 8) && EpiWideOk<Epi>::value) {
+    if (tile == TILE_WIDE_256x256) {
+#ifdef RGP_DEV_KNOBS
+      if (dev_knob("RGP_WVAR", 0) == 1) return launch_wide<256, 256, P, Epi, 1>(p, e, s);
+#endif
+      return launch_wide<256, 256, P, Epi>(p, e, s);
+    }
+    if (tile == TILE_WIDE_512x128) {
+#ifdef RGP_DEV_KNOBS
+      if (dev_knob("RGP_WVAR", 0) == 2) return launch_wide<512, 128, P, Epi, 2>(p, e, s);
+      if (dev_knob("RGP_WVAR", 0) == 3) return launch_wide<512, 128, P, Epi, 1>(p, e, s);
+#endif
+      return launch_wide<512, 128, P, Epi>(p, e, s);
+    }
+  }
+  if (tile == TILE_STAGGER_256x128) {
 #ifdef RGP_DEV_KNOBS
     const int abl = dev_knob("RGP_ABLATE", 0);
     if constexpr (sizeof(T) == 2) { if (abl == 256) return launch_stagger<T, P, Epi, 256>(p, e, s); }
@@ -312,16 +356,15 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
 #endif
     return launch_stagger<T, P, Epi>(p, e, s);
   }
-  if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
-  // latency-bound problems (the per-timestep recurrent convs: M = B*49): 64x64 tiles give 4x the
-  // blocks of 128x128, so more of the 256 CUs have a tile
-  {
-    const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (ksplit == 1 && p.N >= 64 && tiles128 * ksplit < 160) return launch_cfg<T, 64, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
+  switch (tile) {
+#ifdef RGP_DEV_KNOBS
+    case TILE_LOOP_256x128: return launch_cfg<T, 256, 128, 4, 2, G, P, Epi>(p, e, s);
+#endif
+    case TILE_64x64: return launch_cfg<T, 64, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
+    case TILE_128x128: return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s, ksplit);
+    case TILE_128x64: return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
+    default: return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s, ksplit);
   }
-  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s, ksplit);
-  if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
-  return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s, ksplit);
 }
 
 inline IgemmParams make_params(const ConvDesc& d, const void* A, char* ws, int n_img) {

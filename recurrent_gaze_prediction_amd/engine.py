@@ -161,7 +161,9 @@ class GrcnEngine(object):
     """gaze_grcn graph (models/gaze_grcn.py:173-376) at fixed (B, T, P, S, dtype)."""
 
     def __init__(self, batch, n_steps, dim_proj=512, dim_state=128, dtype='bf16', save_for_backward=False,
-                 device='cuda:0'):
+                 device='cuda:0', per_step=False):
+        """per_step=True: the recurrence (and its BPTT) as per-timestep launches even where the persistent
+        kernels apply (RGP_GRCN_PER_STEP): the library's second implementation, used for cross-checks."""
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.B, self.T, self.P, self.S = int(batch), int(n_steps), int(dim_proj), int(dim_state)
@@ -169,8 +171,9 @@ class GrcnEngine(object):
         self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
+            flags = (_lib.RGP_GRCN_SAVE_FOR_BACKWARD if save_for_backward else 0) | (_lib.RGP_GRCN_PER_STEP if per_step else 0)
             _lib.check(self.lib.rgp_grcn_create(ctypes.byref(self._h), self.B, self.T, self.P, self.S,
-                                                _lib.DTYPES[dtype], int(bool(save_for_backward))))
+                                                _lib.DTYPES[dtype], flags))
             nbytes = self.lib.rgp_grcn_workspace_bytes(self._h)
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_grcn_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
@@ -280,6 +283,17 @@ class GrcnEngine(object):
             _lib.check(self.lib.rgp_grcn_forward_rows(self._h, _ptr(rows), _ptr(logits), _ptr(probs),
                                                       _stream_ptr(self.device)))
         return logits, probs
+
+    def status(self):
+        """Wait for the current stream and raise RgpError (RGP_ETIMEOUT) if a persistent ConvGRU launch of this
+        plan lost a group member since the last check (its outputs are NaN)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rgp_grcn_status(self._h, _stream_ptr(self.device)))
+
+    def inject_fault(self, kind):
+        """Test hook (rgp_grcn_inject_fault): kind 'seq' / 'bptt' -- the next persistent launch loses a member."""
+        _lib.check(self.lib.rgp_grcn_inject_fault(self._h, {'seq': _lib.RGP_FAULT_SEQ_LOST_MEMBER,
+                                                            'bptt': _lib.RGP_FAULT_BPTT_LOST_MEMBER}[kind]))
 
     def read_buffer(self, name):
         n = self.lib.rgp_grcn_buffer_elems(self._h, name.encode())
@@ -613,17 +627,24 @@ class CascadeEngine(object):
 class C3DEngine(object):
     """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
 
-    def __init__(self, max_windows, dtype='bf16', device='cuda:0', save_for_backward=False):
+    KERNELS = {'patch': 0, 'igemm': _lib.RGP_C3D_KERNELS_IGEMM,
+               'igemm128': _lib.RGP_C3D_KERNELS_IGEMM | _lib.RGP_C3D_KERNELS_TILE128}
+
+    def __init__(self, max_windows, dtype='bf16', device='cuda:0', save_for_backward=False, kernels='patch'):
+        """kernels: 'patch' (default: the layer-specific kernels for conv2a..conv4b), 'igemm' (the general
+        implicit-GEMM / filter-gradient kernels for every layer, tile by problem size) or 'igemm128' (the same on
+        the 128x128 tile loop only) -- rgp_c3d_create_ex flags; the second family exists for cross-checks."""
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.max_windows = int(max_windows)
         self.dtype = dtype
+        self.kernels = kernels
         self.save_for_backward = bool(save_for_backward)
         self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_c3d_create_ex(ctypes.byref(self._h), self.max_windows, _lib.DTYPES[dtype],
-                                                  int(self.save_for_backward)))
+                                                  int(self.save_for_backward) | self.KERNELS[kernels]))
             nbytes = self.lib.rgp_c3d_workspace_bytes(self._h)
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.rgp_c3d_bind_workspace(self._h, _ptr(self.workspace), nbytes, _stream_ptr(self.device)))
@@ -751,6 +772,10 @@ class C3DEngine(object):
                                                         frames.shape[2], arr, n, _ptr(mean_cube), _ptr(video),
                                                         _stream_ptr(self.device)))
         return video
+
+    def layer_kernel_name(self, layer, n_windows):
+        """Kernel instantiation that runs layer's forward at n_windows windows per launch (as a profiler names it)."""
+        return self.lib.rgp_c3d_layer_kernel_name(self._h, int(layer), int(n_windows)).decode()
 
     def read_layer(self, layer, n_windows):
         n = self.lib.rgp_c3d_layer_elems(self._h, layer, n_windows)

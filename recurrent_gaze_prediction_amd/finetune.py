@@ -68,27 +68,32 @@ class EndToEndGaze(object):
             self.c3d.forward(video[w0:w0 + n], want_features=False, want_rows=True, out_rows=self.rows[w0 * 49:(w0 + n) * 49])
         return self.head.forward_rows(self.rows, want_probs=want_probs)
 
-    def backward(self, video, logits, probs, labels):
-        """Fills both engines' flat_grads; returns the loss (device scalar)."""
+    def backward(self, video, logits, probs, labels, finish=True):
+        """Fills both engines' flat_grads; returns the loss (device scalar).  With a process group attached the
+        gradient buckets are all-reduced on a side stream while the conv stack differentiates; finish=True (default)
+        joins them before returning, so the gradients a caller reads are the reduced ones.  finish=False leaves the
+        collectives in flight (the caller must call reducer.finish() before touching flat_grads)."""
         from .engine import l2_loss, softmax_xent
+        red = getattr(self, 'reducer', None)
+        if red is not None and red.pending:
+            red.finish()                              # collectives of an earlier backward(finish=False) still own flat_grads
         labels = labels.reshape(self.B, self.T, 49, 49).contiguous()
         if self.loss_type == 'xentropy':
             loss = softmax_xent(logits, labels, want_probs=False)[2]
         else:
             loss = l2_loss(logits, labels, self.F)
         self.head.backward(logits, probs, labels, self.loss_type)
-        red = getattr(self, 'reducer', None)
         if red is not None:
             red.reduce(self.head.flat_grads)          # 12 MB over xGMI while the conv stack differentiates
         self.head.backward_input(self.d_rows)
         _c3d_backward_chunks(self, video, self.d_rows, red)
+        if red is not None and finish:
+            red.finish()                              # every bucket reduced (mean) before anyone reads the gradients
         return loss
 
     def train_step(self, video, labels, lr, max_grad_norm=10.0):
         logits, probs = self.forward(video, want_probs=self.loss_type == 'xentropy')
-        loss = self.backward(video, logits, probs, labels)
-        if getattr(self, 'reducer', None) is not None:
-            self.reducer.finish()                     # every bucket reduced (mean) before the global-norm clip
+        loss = self.backward(video, logits, probs, labels)       # (joins the all-reduces: the clip needs them all)
         gnorm = adam_clip_step_multi(self.engines, self.global_step, lr, max_grad_norm)
         self.global_step += 1
         return loss, gnorm
@@ -134,22 +139,25 @@ class EndToEndCascade(object):
             self.feats[w0:w0 + n] = self.c3d.forward(video[w0:w0 + n])[0]
         return self.head.forward(frames, self.feats.reshape(self.B, self.T, 1024, 7, 7))
 
-    def backward(self, video, maps, labels):
+    def backward(self, video, maps, labels, finish=True):
+        """As EndToEndGaze.backward: returns after the gradient all-reduces have been joined unless finish=False."""
         from .engine import l2_loss
+        red = getattr(self, 'reducer', None)
+        if red is not None and red.pending:
+            red.finish()
         labels = labels.reshape(maps.shape).contiguous()
         loss = l2_loss(maps, labels, self.F)
         _, d_rows = self.head.backward(maps, labels, want_d_rows=True)
-        red = getattr(self, 'reducer', None)
         if red is not None:
             red.reduce(self.head.flat_grads)          # 216 MB: the largest bucket starts first
         _c3d_backward_chunks(self, video, d_rows, red)
+        if red is not None and finish:
+            red.finish()
         return loss
 
     def train_step(self, video, frames, labels, lr, max_grad_norm=10.0):
         maps = self.forward(video, frames)
         loss = self.backward(video, maps, labels)
-        if getattr(self, 'reducer', None) is not None:
-            self.reducer.finish()
         gnorm = adam_clip_step_multi(self.engines, self.global_step, lr, max_grad_norm)
         self.global_step += 1
         return loss, gnorm

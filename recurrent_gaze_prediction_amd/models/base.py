@@ -118,6 +118,8 @@ class ModelBase(object):
         if getattr(self, 'flip_rng', None) is not None:
             ck['flip_seed'] = getattr(self, 'flip_seed', None)
             ck['flip_rng_state'] = self.flip_rng.get_state()
+        # dropout sites: Philox key + draw counter, so a resumed run continues the mask stream instead of replaying it
+        ck['dropout'] = [{'seed': d.seed, 'draws': d.draws, 'keep_prob': d.keep_prob} for d in self._dropout_sites()]
         torch.save(ck, path)
         with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
             f.write(os.path.basename(path) + '\n')
@@ -135,7 +137,19 @@ class ModelBase(object):
         if ck.get('flip_rng_state') is not None and getattr(self, 'flip_rng', None) is not None:
             self.flip_rng.set_state(ck['flip_rng_state'])
             self.flip_seed = ck.get('flip_seed', getattr(self, 'flip_seed', None))
+        for d, st in zip(self._dropout_sites(), ck.get('dropout', [])):
+            d.seed, d.draws = int(st['seed']), int(st['draws'])
         log.info(" [Checkpoint] Successfully loaded from %s", checkpoint_path)
+
+    def _dropout_sites(self):
+        """DropoutSite objects of the model's engine(s) (fc-GRU: the projected features; cascade: fc1), if any."""
+        sites = []
+        e = getattr(self, 'engine', None)
+        for obj in (e, getattr(e, 'net', None)):
+            d = getattr(obj, 'dropout', None)
+            if d is not None and hasattr(d, 'draws') and d not in sites:
+                sites.append(d)
+        return sites
 
     def load_model_checkpoint(self, checkpoint_dir):
         checkpoint_dir = os.path.join(checkpoint_dir, "model")

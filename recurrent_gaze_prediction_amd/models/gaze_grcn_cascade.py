@@ -116,8 +116,8 @@ class GazePredictionGRCN(GazePredictionGRU):
         engine = _CascadeAdapter(model)
         model.variables = synthetic.cascade_params(getattr(model.config, 'init_seed', 0), engine.net.image_hw)
         engine.set_weights(model.variables)
-        engine.net.dropout.configure(getattr(model.config, 'train_keep_prob', 0.5),
-                                     seed=(getattr(model.config, 'init_seed', 0) << 20) + 0x2545f491)
+        from .gaze_rnn import dropout_seed
+        engine.net.dropout.configure(getattr(model.config, 'train_keep_prob', 0.5), seed=dropout_seed(model.config, 0x2545f491))
         if net is not None:
             net['variables'] = model.variables
         return engine

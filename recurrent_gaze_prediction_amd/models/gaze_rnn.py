@@ -43,6 +43,14 @@ class GRUModelConfig(BaseModelConfig):
         self.train_keep_prob = 0.5     # keep_prob single_step feeds when training (gaze_rnn.py:529)
 
 
+def dropout_seed(config, salt):
+    """Philox key of a model's dropout site: data-parallel ranks must draw DIFFERENT masks (as they mirror different
+    clips, flip_seed below), so the rank is mixed in; the key and the draw counter are saved in checkpoints."""
+    from .. import dist as rdist
+    rank = rdist.env_world()[0]
+    return ((int(getattr(config, 'init_seed', 0)) << 20) + int(salt) + 0x9E3779B1 * rank) & 0x7fffffffffffffff
+
+
 class GazePredictionGRU(ModelBase):
     """gaze_rnn.py:66-680."""
 
@@ -105,8 +113,7 @@ class GazePredictionGRU(ModelBase):
         model.variables = synthetic.fcgru_params(getattr(model.config, 'init_seed', 0), model.gazemap_height,
                                                  model.gazemap_width)
         engine.set_weights(model.variables)
-        engine.dropout.configure(getattr(model.config, 'train_keep_prob', 0.5),
-                                 seed=(getattr(model.config, 'init_seed', 0) << 20) + 0x5bd1e995)
+        engine.dropout.configure(getattr(model.config, 'train_keep_prob', 0.5), seed=dropout_seed(model.config, 0x5bd1e995))
         net['variables'] = model.variables
         return engine
 
@@ -230,13 +237,23 @@ class GazePredictionGRU(ModelBase):
         self.predict(batch_c3d, batch_images, train=train_mode)
         self.loss = loss = self.compute_loss(batch_maps)
         if train_mode:
+            # a diverged step must be loud: ReLU / max-pool (maxNum semantics) turn a NaN into a finite value further down
+            # the graph, so the loss and the pre-clip gradient norm are the places to look
+            if not np.isfinite(loss):
+                raise FloatingPointError('non-finite training loss %r at step %d' % (loss, self.current_step))
             labels = torch.as_tensor(np.ascontiguousarray(batch_maps, np.float32)).to(self.session.device)
             self.train_op(self.predicted_gazemaps_logit, self.predicted_gazemaps, labels.reshape(self.predicted_gazemaps_logit.shape).contiguous())
         step = self.current_step
         dt = time.time() - _start_time
         if (not train_mode) or step % max(1, self.config.steps_per_logprint) == 0:
-            log.info(" [%5s step %4d] batch total-loss: %.5f (%.3f sec/batch, %.3f instances/sec) (lr=%.3g)",
-                     'train' if train_mode else 'val', step, loss, dt, self.batch_size / dt, self.current_learning_rate)
+            gn = ''
+            if train_mode and getattr(self, 'grad_norm', None) is not None:
+                g = float(self.grad_norm.item())
+                if not np.isfinite(g):
+                    raise FloatingPointError('non-finite gradient norm %r at step %d' % (g, step))
+                gn = ' (|g|=%.3g)' % g
+            log.info(" [%5s step %4d] batch total-loss: %.5f (%.3f sec/batch, %.3f instances/sec) (lr=%.3g)%s",
+                     'train' if train_mode else 'val', step, loss, dt, self.batch_size / dt, self.current_learning_rate, gn)
         return step
 
     def generate(self, dataset, max_instances=50):
@@ -263,6 +280,9 @@ class GazePredictionGRU(ModelBase):
             fixationmap_list.extend(batch_fixmaps)
             images_list.extend(np.concatenate(batch_images))
             filename_list.extend(batch_filename)
+        status = getattr(self.engine, 'status', None)
+        if callable(status):
+            status()              # RGP_ETIMEOUT of a persistent ConvGRU launch (its maps are NaN) raises here
         pred_gazemap_list = np.vstack(pred_gazemap_list).reshape([-1, GH, GW])
         gt_gazemap_list = np.vstack(gt_gazemap_list).reshape([-1, GH, GW])
         c3d_list = np.vstack(c3d_list).reshape([-1, 1024, 7, 7])

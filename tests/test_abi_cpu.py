@@ -69,6 +69,39 @@ def test_c3d_plan_host_only():
     assert lib.rgp_c3d_create(ctypes.byref(h), 0, _lib.RGP_BF16) == -1
 
 
+def test_c3d_kernel_names_and_flags_host_only():
+    """rgp_c3d_layer_kernel_name restates nothing: it asks the dispatcher (igemm_tile_choice) which kernel a layer runs."""
+    lib = _lib.load()
+
+    def names(flags, n, dtype=_lib.RGP_BF16, max_windows=1024):
+        h = ctypes.c_void_p()
+        assert lib.rgp_c3d_create_ex(ctypes.byref(h), max_windows, dtype, flags) == 0, lib.rgp_last_error()
+        out = [lib.rgp_c3d_layer_kernel_name(h, i, n).decode() for i in range(8)]
+        lib.rgp_c3d_destroy(h)
+        return out
+    d = names(0, 1024)
+    assert d[0].startswith('conv1a_pool_bf16_kernel')
+    assert d[1] == 'conv_patch_bf16_kernel<64,128,56,16,pool8>' and d[2] == 'conv_patch_bf16_kernel<128,256,28,8,pool1>'
+    assert d[3] == 'conv_patch_bf16_kernel<256,256,28,8,pool8>'
+    assert d[4] == 'conv_patch14_bf16_kernel<256,pool1>' and d[5] == 'conv_patch14_bf16_kernel<512,pool8>'
+    assert d[6] == d[7] == 'igemm_stagger_kernel<256x128,bf16,pool1>'
+    g = names(_lib.RGP_C3D_KERNELS_IGEMM, 1024)
+    assert g[1] == 'igemm_wide_kernel<512x128,bf16,pool8>' and g[3] == 'igemm_wide_kernel<256x256,bf16,pool8>'
+    assert g[4] == 'igemm_wide_kernel<256x256,bf16,pool1>' and g[6] == d[6]
+    t = names(_lib.RGP_C3D_KERNELS_IGEMM | _lib.RGP_C3D_KERNELS_TILE128, 1024)
+    assert all(x.startswith('igemm_kernel<128x128,bf16') for x in t[1:])
+    small = names(0, 2, max_windows=2)
+    assert small[1].startswith('conv_patch_bf16_kernel') and small[6] == 'igemm_kernel<64x64,bf16,pool1>'
+    f32 = names(0, 1024, dtype=_lib.RGP_F32)
+    assert f32[0] == 'igemm_kernel<128x64,f32,pool4>' and f32[3] == 'igemm_stagger_kernel<256x128,f32,pool8>'
+    h = ctypes.c_void_p()
+    assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, 8) == -1                      # unknown flag
+    assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, _lib.RGP_C3D_KERNELS_TILE128) == -1
+    assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, 4) == -1           # unknown flag
+    assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, _lib.RGP_GRCN_PER_STEP) == 0
+    lib.rgp_grcn_destroy(h)
+
+
 def test_engine_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -64,68 +64,79 @@ def test_c3d_chunking_equals_single_pass(gpu, c3d_case):
     assert torch.equal(fa, fb)
 
 
-@pytest.mark.parametrize('env', [{'RGP_TILE': '0'}, {'RGP_HALO': '1'}, {'RGP_HALO': '2'}, {'RGP_TILE': '1'}])
-def test_alternative_conv_kernels_stay_correct(gpu, env):
-    """The 128x128 tile loop, the 256x128 simple loop and the LDS-halo direct kernel are selected by
-    environment knobs read once per process, so each runs in a child process: 8 windows (enough rows
-    for every variant's size threshold) against the default path's features, bit-for-bit where the
-    summation order is the same and within bf16 tolerance otherwise."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, torch, numpy as np
-sys.path.insert(0, %r)
-from recurrent_gaze_prediction_amd import synthetic as syn
-from recurrent_gaze_prediction_amd.engine import C3DEngine
-eng = C3DEngine(8, dtype='bf16'); eng.set_weights(syn.c3d_params(21))
-v = torch.tensor(syn.video_windows(23, 8), device='cuda')
-f, _ = eng.forward(v); torch.cuda.synchronize()
-np.save(sys.argv[1], f.cpu().numpy())
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import tempfile
-    outs = []
-    for e in ({}, env):
-        with tempfile.NamedTemporaryFile(suffix='.npy') as tf:
-            r = subprocess.run([sys.executable, '-c', code, tf.name], env=dict(os.environ, **e), capture_output=True,
-                               text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs.append(np.load(tf.name))
-    assert rel_err(outs[1], outs[0]) < 2e-2 and np.isfinite(outs[1]).all()
+def _check_layers_against_oracle(eng, rows, c3d_case, n=2, tol=None):
+    from recurrent_gaze_prediction_amd.engine import C3D_LAYER_NAMES
+    _, _, _, ref_acts = c3d_case
+    tol = tol or TOL['bf16']
+    for i, name in enumerate(C3D_LAYER_NAMES):
+        ref = np.transpose(ref_acts[name], (0, 2, 3, 4, 1))          # NCDHW -> NDHWC
+        if i == 7:
+            got = rows[:n * 49].float().cpu().numpy().reshape(n, 7, 7, 2, 512).transpose(0, 3, 1, 2, 4)
+        else:
+            got = eng.read_layer(i, n).cpu().numpy().reshape(ref.shape)
+        e = rel_err(got, ref)
+        assert e < tol, '%s rel err %.3e' % (name, e)
 
 
-@pytest.mark.parametrize('env,exact', [({'RGP_PERSIST': '0'}, True), ({'RGP_TILE': '0'}, False)])
-def test_persistent_tile_loop_ragged(gpu, env, exact):
-    """85 windows: conv4a has 66 640 rows = 260.3 row tiles, so the persistent staggered kernel walks several
-    tiles per block and ends on a partially valid one.  One block per tile (RGP_PERSIST=0) must give the same
-    bits; the 128x128 tile loop the same values within bf16 tolerance."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    code = r'''
-import sys, torch, numpy as np
-sys.path.insert(0, %r)
-from recurrent_gaze_prediction_amd import synthetic as syn
-from recurrent_gaze_prediction_amd.engine import C3DEngine
-eng = C3DEngine(85, dtype='bf16'); eng.set_weights(syn.c3d_params(21))
-torch.manual_seed(5)
-v = torch.rand(85, 16, 112, 112, 3, device='cuda') - 0.5
-f, _ = eng.forward(v); torch.cuda.synchronize()
-np.save(sys.argv[1], f.cpu().numpy())
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for e in ({}, env):
-        with tempfile.NamedTemporaryFile(suffix='.npy') as tf:
-            r = subprocess.run([sys.executable, '-c', code, tf.name], env=dict(os.environ, **e), capture_output=True,
-                               text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs.append(np.load(tf.name))
-    assert np.isfinite(outs[1]).all() and np.abs(outs[0]).max() > 0
-    if exact:
-        assert np.array_equal(outs[0], outs[1])
-    else:
-        assert rel_err(outs[1], outs[0]) < 2e-2
+@pytest.mark.parametrize('kernels', ['igemm', 'igemm128'])
+def test_igemm_kernel_family_matches_oracle_small(gpu, c3d_case, kernels):
+    """RGP_C3D_KERNELS_IGEMM (+ _TILE128): the library's second implementation of conv2a..conv4b -- the general
+    implicit-GEMM kernels -- on the oracle case (2 windows: the non-persistent tile loops, 128x128 down to 64x64 by
+    problem size), every layer against torch_ref.c3d_forward."""
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, v, ref_feat, _ = c3d_case
+    eng = C3DEngine(2, dtype='bf16', device=gpu, kernels=kernels)
+    eng.set_weights(p)
+    for i in range(1, 8):
+        assert eng.layer_kernel_name(i, 2).startswith('igemm_kernel<'), eng.layer_kernel_name(i, 2)
+    assert eng.layer_kernel_name(1, 2).startswith('igemm_kernel<128x128')
+    feats, rows = eng.forward(torch.tensor(v, device=gpu), want_features=True, want_rows=True)
+    _check_layers_against_oracle(eng, rows, c3d_case)
+    assert rel_err(feats.cpu().numpy(), ref_feat) < TOL['bf16']
+
+
+def test_igemm_kernel_family_matches_oracle_at_scale(gpu, c3d_case):
+    """The persistent tiles of the implicit-GEMM family (igemm_wide 512x128 on conv2a, 256x256 on conv3a..conv4b, the
+    staggered 256x128 kernel on conv5a/b) need >= 1024 tiles: 768 windows whose first two are the oracle case.  Every
+    layer of that run is compared DIRECTLY with torch_ref.c3d_forward, and all 96 replicas of the 8 distinct windows must
+    agree bit for bit (windows are independent; a tile never mixes them)."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, v2, ref_feat, _ = c3d_case
+    v8 = torch.tensor(np.concatenate([v2, syn.video_windows(23, 6)]), device=gpu)
+    eng = C3DEngine(768, dtype='bf16', device=gpu, kernels='igemm')
+    eng.set_weights(p)
+    names = [eng.layer_kernel_name(i, 768) for i in range(8)]
+    assert names[1].startswith('igemm_wide_kernel<512x128') and names[6].startswith('igemm_stagger_kernel<256x128'), names
+    assert all(nm.startswith('igemm_wide_kernel<256x256') for nm in names[2:6]), names
+    f, rows = eng.forward(v8.repeat(96, 1, 1, 1, 1), want_features=True, want_rows=True)
+    assert torch.isfinite(f).all()
+    _check_layers_against_oracle(eng, rows, c3d_case)
+    assert rel_err(f[:2].cpu().numpy(), ref_feat) < TOL['bf16']
+    assert torch.equal(f.reshape(96, 8, -1), f[:8].reshape(1, 8, -1).expand(96, 8, f[0].numel()))
+
+
+def test_igemm_family_ragged_window_count(gpu, c3d_case):
+    """85 windows: conv4a / conv4b have 66 640 rows = 260.3 row tiles of 256, so the persistent staggered kernel (the
+    tile the implicit-GEMM family picks at this size) walks several tiles per block and ends on a partially valid one.
+    The first two windows are the oracle case (every layer against torch_ref.c3d_forward); the other 83 repeat 8
+    distinct windows, and window independence makes that check exact: replica k must equal windows 0..7 bit for bit,
+    the last, partial replica included."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p, v2, ref_feat, _ = c3d_case
+    v8 = torch.tensor(np.concatenate([v2, syn.video_windows(23, 6)]), device=gpu)
+    v85 = torch.cat([v8.repeat(10, 1, 1, 1, 1), v8[:5]]).contiguous()
+    eng = C3DEngine(85, dtype='bf16', device=gpu, kernels='igemm')
+    eng.set_weights(p)
+    assert eng.layer_kernel_name(4, 85).startswith('igemm_stagger_kernel<256x128'), eng.layer_kernel_name(4, 85)
+    f, rows = eng.forward(v85, want_features=True, want_rows=True)
+    assert torch.isfinite(f).all()
+    _check_layers_against_oracle(eng, rows, c3d_case)
+    # replicas: windows 8k .. 8k+7 repeat windows 0 .. 7 (the last, partial group too)
+    for k in range(1, 11):
+        m = min(8, 85 - 8 * k)
+        assert torch.equal(f[8 * k:8 * k + m], f[:m]), k
 
 
 def test_full_size_launch_chain_is_clip_independent(gpu, c3d_case):

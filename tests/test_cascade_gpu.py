@@ -103,6 +103,57 @@ def test_cascade_backward_matches_autograd(gpu, dtype):
     assert rel_err(d_rows.cpu().numpy(), ref_rows) < (1e-3 if dtype == 'f32' else 1e-1)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_cascade_at_its_configured_length_T35(gpu, dtype):
+    """BASELINE config 5 is "35-frame clips": B = 2, T = 35 -- the 256-channel bottom cell and the 49x49 top cell
+    (5x5, 3 units) through 35 recurrent steps, forward per stage and the BPTT of both cells against float64 autograd
+    (gaze_grcn_cascade.py:289-313, 346-382).  f32 <= 1e-3; bf16: stage tolerances of the T = 3 test, gradients <= 6e-2 RMS."""
+    from recurrent_gaze_prediction_amd.engine import CascadeEngine
+    B, T = 2, 35
+    p = syn.cascade_params(331)
+    rs = np.random.RandomState(332)
+    frames = rs.rand(B, T, 98, 98, 3).astype(np.float32)
+    c3d = syn.c3d_features(333, B, T)
+    gt, _ = syn.gaze_maps(334, B, T)
+    gt = (gt / gt.max()).astype(np.float32)
+    tp = to_t(p)
+    keys = [k for k in tp if k != 'ShallowNet']
+    for k in keys:
+        tp[k].requires_grad_(True)
+    x = torch.tensor(c3d, dtype=torch.float64, requires_grad=True)
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        maps_ref, mid = torch_ref.cascade_forward(torch.tensor(frames, dtype=torch.float64), x, tp, want_all=True)
+        torch_ref.gaze_loss(maps_ref, torch.tensor(gt, dtype=torch.float64), 'l2').backward()
+    finally:
+        torch.set_num_threads(old)
+    eng = CascadeEngine(B, T, 98, dtype=dtype, device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    maps = eng.forward(torch.tensor(frames, device=gpu), torch.tensor(c3d, device=gpu))
+    stages = {'frm_sal': mid['sal'], 'rcn_outputs': mid['bottom'], 'rcn_upsampled_outputs': mid['up'], 'gaze_rcn_outputs': mid['top']}
+    errs = {k: rel_err(eng.read_buffer(k).cpu().numpy(), v.detach().numpy()) for k, v in stages.items()}
+    errs['maps'] = rel_err(maps.cpu().numpy(), maps_ref.detach().numpy())
+    # the last step is the hard one for bf16 (35 steps of compounding rounding)
+    errs['last_top_state'] = rel_err(eng.read_buffer('gaze_rcn_outputs').cpu().numpy().reshape(B, T, 49, 49, 3)[:, -1],
+                                     mid['top'].detach().numpy().reshape(B, T, 49, 49, 3)[:, -1])
+    tol = dict(TOL[dtype], last_top_state=TOL[dtype]['gaze_rcn_outputs'])
+    bad = {k: e for k, e in errs.items() if not e < (3 * tol[k] if dtype == 'f32' else tol[k])}
+    assert not bad, (bad, errs)
+    grads, d_rows = eng.backward(maps, torch.tensor(gt, device=gpu), want_d_rows=True)
+    tol_max, tol_rms = (3e-3, 1e-3) if dtype == 'f32' else (3e-1, 6e-2)
+    gerrs = {}
+    for field, key in CascadeEngine.KEYS:
+        ref = tp[key].grad.numpy()
+        got = grads[field].cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all() and np.abs(ref).max() > 0, key
+        gerrs[key] = (rel_err(got, ref), float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())))
+    bad = {k: e for k, e in gerrs.items() if not (e[0] < tol_max and e[1] < tol_rms)}
+    assert not bad, (bad, gerrs)
+    ref_rows = x.grad.reshape(B * T, 512, 2, 49).permute(0, 3, 2, 1).reshape(B * T * 49, 1024).numpy()
+    assert rel_err(d_rows.cpu().numpy(), ref_rows) < (3e-3 if dtype == 'f32' else 1e-1)
+
+
 def test_cascade_training_through_the_model_api(gpu, tmp_path):
     """single_step(train_mode=True) on the cascade class: l2 loss, backward, clipped TF-Adam; the loss on a fixed
     validation batch goes down and the state dict carries the updated variables (ShallowNet unchanged)."""

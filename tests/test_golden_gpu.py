@@ -176,3 +176,56 @@ def test_softmax_xent_kernel_known_answers(gpu):
     z7 = torch.randn(5, 7, 7, device=gpu)                       # 7x7 maps (gaze_rnn77 style)
     p7, _, _ = softmax_xent(z7)
     assert torch.allclose(p7, torch.softmax(z7.reshape(5, -1), -1).reshape(5, 7, 7), atol=1e-6)
+
+
+def test_end_to_end_bf16_metrics_gate_T16(gpu):
+    """The north-star acceptance gate on its own workload: 3 clips x T = 16 of synthetic video -> C3D conv1a..5b (bf16
+    patch kernels) -> rows -> gaze_grcn head (bf16, persistent ConvGRU) -> per-frame softmax, against the fp32 CPU oracle
+    of the SAME chain (torch_ref.c3d_forward -> grcn_forward): cc, sim, AUC_Judd, AUC_Borji of the 48 maps within +-1e-3
+    (evaluation_metrics.py:239-295; seeds as in test_saliency_metrics_within_1e3_of_oracle).  Also checked with trained-
+    looking maps: the random-init head gives nearly flat maps, so a second head whose output layer is scaled up (logit
+    range of a few units, peaked maps) goes through the same gate."""
+    from recurrent_gaze_prediction_amd.engine import C3DEngine, GrcnEngine
+    B, T = 3, 16
+    cp = syn.c3d_params(65, scale='he')
+    video = syn.video_windows(66, B * T)
+    gt, centres = syn.gaze_maps(67, B, T)
+    fix = syn.fixation_maps(68, centres)
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        with torch.no_grad():
+            feat_ref = torch_ref.c3d_forward(torch.tensor(video), {k: torch.tensor(v) for k, v in cp.items()})
+    finally:
+        torch.set_num_threads(old)
+    c3d = C3DEngine(B * T, dtype='bf16', device=gpu)
+    c3d.set_weights(cp)
+    feats, rows = c3d.forward(torch.tensor(video, device=gpu), want_features=True, want_rows=True)
+    e_feat = rel_err(feats.cpu().numpy(), feat_ref.numpy())
+    assert e_feat < 3e-2, e_feat
+    flat = lambda a: list(np.asarray(a).reshape(B * T, 49, 49))
+    report = {}
+    for label, out_scale in (('random-init head', 1.0), ('peaked maps', 40.0)):
+        hp = syn.grcn_params(61, T, gru_std=0.05, random_bn=True)
+        hp['out_W'] = hp['out_W'] * out_scale
+        with torch.no_grad():
+            ref_logits = torch_ref.grcn_forward(feat_ref.reshape(B, T, 1024, 7, 7), {k: torch.tensor(v) for k, v in hp.items()})
+            ref = torch_ref.softmax_maps(ref_logits).numpy()
+        head = GrcnEngine(B, T, dtype='bf16', device=gpu)
+        head.set_weights(hp)
+        logits, probs = head.forward_rows(rows)
+        head.status()
+        got = probs.cpu().numpy()
+        assert np.isfinite(got).all()
+        spread = float(ref_logits.max() - ref_logits.min())
+        for metric in ('cc', 'sim', 'AUC_Borji', 'AUC_Judd'):
+            scores = []
+            for maps in (ref, got):
+                np.random.seed(7)
+                if metric == 'AUC_Judd':
+                    scores.append(np.mean([em.saliency_score_single(metric, m, g, f) for m, g, f in zip(flat(maps), flat(gt), flat(fix))]))
+                else:
+                    scores.append(em.saliency_score(metric, flat(maps), flat(gt), flat(fix)))
+            report[(label, metric)] = (scores[0], scores[1], spread)
+    bad = {k: v for k, v in report.items() if not abs(v[0] - v[1]) < 1e-3}
+    assert not bad, (bad, report)

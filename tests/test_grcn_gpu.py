@@ -109,3 +109,107 @@ def test_persistent_sequence_kernel_group_shapes(gpu, B, T):
     # a second call on the same plan gives the same result (phase counters are re-zeroed per launch)
     logits2, _ = eng.forward(torch.tensor(x, device=gpu))
     assert torch.equal(logits, logits2)
+
+
+@pytest.mark.parametrize('B,T', [(2, 6), (33, 3)])
+def test_per_step_recurrence_agrees_with_persistent_kernels(gpu, B, T):
+    """RGP_GRCN_PER_STEP: the same bf16 plan with the recurrence (and its BPTT) as per-timestep launches -- the path
+    f32 plans and other cell widths always take -- against the oracle AND against the persistent kernels on the same
+    inputs: states, logits and every gradient (they differ only by the K-split summation order feeding bf16 rounding)."""
+    from oracle import grcn
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    p = syn.grcn_params(71 + B, T, gru_std=0.05, random_bn=True)
+    x = syn.c3d_features(72 + B, B, T)
+    gt, _ = syn.gaze_maps(73 + B, B, T)
+    g = torch.tensor(grcn.normalize_probability_map(gt).astype(np.float32), device=gpu)
+    ref_logits, ref_h, _ = oracle_forward(x, p)
+    out = {}
+    for per_step in (False, True):
+        eng = GrcnEngine(B, T, dtype='bf16', device=gpu, save_for_backward=True, per_step=per_step)
+        eng.set_weights(p)
+        logits, probs = eng.forward(torch.tensor(x, device=gpu))
+        grads = {k: v.cpu().numpy().copy() for k, v in eng.backward(logits, probs, g).items()}
+        h = eng.read_buffer('rcn_outputs').cpu().numpy().reshape(ref_h.shape)
+        assert rel_err(h, ref_h) < TOL_H_MAX['bf16'] and rel_err(logits.cpu().numpy(), ref_logits) < TOL['bf16'], per_step
+        out[per_step] = (h, logits.cpu().numpy(), grads)
+        if per_step:
+            from recurrent_gaze_prediction_amd._lib import RgpError
+            with pytest.raises(RgpError):
+                eng.inject_fault('seq')                    # no persistent kernel on this plan
+    (h0, l0, g0), (h1, l1, g1) = out[False], out[True]
+    assert rel_err(h0, h1) < 2e-2 and rel_err(l0, l1) < 1e-2
+    for k in g0:
+        if k == 'out_b':
+            continue
+        e = np.linalg.norm(g0[k] - g1[k]) / max(np.linalg.norm(g1[k]), 1e-30)
+        assert e < 2e-2, (k, e)
+
+
+def test_lost_group_member_is_loud(gpu):
+    """A persistent ConvGRU launch whose group never completes (fault injection: one of the 8 workgroups of group 0
+    leaves at once -- what a second resident launch on the device would cause) must not return finite maps: after the
+    ~1 s time-out every logit / map of the group's clips is NaN, the plan reports RGP_ETIMEOUT (status() and the next
+    call), the other groups' clips are intact, and the plan works again afterwards.  Same for the BPTT kernel."""
+    from oracle import grcn
+    from recurrent_gaze_prediction_amd import _lib
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    B, T = 3, 4                                            # one clip per group: group 0 = clip 0
+    p = syn.grcn_params(81, T, gru_std=0.05, random_bn=True)
+    x = torch.tensor(syn.c3d_features(82, B, T), device=gpu)
+    gt, _ = syn.gaze_maps(83, B, T)
+    g = torch.tensor(grcn.normalize_probability_map(gt).astype(np.float32), device=gpu)
+    eng = GrcnEngine(B, T, dtype='bf16', device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    good_logits, good_probs = [t.clone() for t in eng.forward(x)]
+    eng.status()                                           # clean
+    eng.inject_fault('seq')
+    logits, probs = eng.forward(x)
+    with pytest.raises(_lib.RgpError, match='lost a group member'):
+        eng.status()
+    assert torch.isnan(logits[0]).all() and torch.isnan(probs[0]).all()
+    assert torch.equal(logits[1:], good_logits[1:])        # the other groups never noticed
+    eng.status()                                           # reported once, then clear
+    # the error also surfaces on the next call of a caller that never asks
+    eng.inject_fault('seq')
+    eng.forward(x)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.RgpError, match='lost a group member'):
+        eng.forward(x)
+    logits2, _ = eng.forward(x)
+    assert torch.equal(logits2, good_logits)               # the plan is usable again, bit for bit
+    # BPTT
+    good = {k: v.clone() for k, v in eng.backward(good_logits, good_probs, g).items()}
+    eng.forward(x)
+    eng.inject_fault('bptt')
+    grads = eng.backward(good_logits, good_probs, g)
+    with pytest.raises(_lib.RgpError, match='lost a group member'):
+        eng.status()
+    assert not torch.isfinite(grads['GRU_Conv_Wz']).all() and not torch.isfinite(grads['proj_c3d_W']).all()
+    eng.forward(x)
+    again = eng.backward(good_logits, good_probs, g)
+    for k in good:
+        assert torch.allclose(again[k], good[k], rtol=1e-4, atol=1e-6 * float(good[k].abs().max())), k
+
+
+def test_persistent_launches_from_two_streams_are_serialised(gpu):
+    """Two plans driven from two streams of one process: the library orders their persistent launches (one in flight
+    per device), so neither times out and both give their single-stream results."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    B, T = 64, 16                                          # 32 groups: a launch fills all 256 CUs
+    p = syn.grcn_params(91, T, gru_std=0.05, random_bn=True)
+    xs = [torch.tensor(syn.c3d_features(92 + i, B, T), device=gpu) for i in range(2)]
+    engs = [GrcnEngine(B, T, dtype='bf16', device=gpu) for _ in range(2)]
+    for e in engs:
+        e.set_weights(p)
+    ref = [e.forward(x)[0].clone() for e, x in zip(engs, xs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    outs = [None, None]
+    for rep in range(3):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = engs[i].forward(xs[i])[0]
+    torch.cuda.synchronize()
+    for i in range(2):
+        engs[i].status()
+        assert torch.equal(outs[i], ref[i]), i
