@@ -35,31 +35,10 @@ C3D_LAYERS = [('conv1a', 3, 64, 16, 112), ('conv2a', 64, 128, 16, 56), ('conv3a'
               ('conv3b', 256, 256, 8, 28), ('conv4a', 256, 512, 4, 14), ('conv4b', 512, 512, 4, 14),
               ('conv5a', 512, 512, 2, 7), ('conv5b', 512, 512, 2, 7)]
 C3D_FLOPS = {n: 2.0 * d * h * h * 27 * ci * co for n, ci, co, d, h in C3D_LAYERS}     # per window
+C3D_NAMES = [l[0] for l in C3D_LAYERS]
 HEAD_FLOPS = {'proj': 51.38e6, 'xconv': 173.41e6, 'convgru_seq': 43.35e6, 'head': 20.07e6 + 54.17e6 + 90.35e6 + 0.06e6}
 HEAD_FLOPS_FRAME = 432.79e6
 C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
-# kernel instantiation that executes each C3D layer at `n` windows per launch (mirrors launch_igemm in csrc/rgp_host.h)
-C3D_POOL = {'conv1a': 4, 'conv2a': 8, 'conv3a': 1, 'conv3b': 8, 'conv4a': 1, 'conv4b': 8, 'conv5a': 1, 'conv5b': 1}
-
-
-def c3d_kernel_group(name, n_windows, dtype='bf16', train=False):
-    """Kernel (template instance) that runs a conv layer: the dispatch of rgp_c3d.hip / rgp_host.h restated."""
-    ci, co, d, h = next((ci, co, d, h) for nm, ci, co, d, h in C3D_LAYERS if nm == name)
-    if name == 'conv1a' and dtype == 'bf16':
-        return 'conv1a_pool_bf16_kernel'
-    if dtype == 'bf16' and name in ('conv2a', 'conv3a', 'conv3b'):                    # conv_patch.hip.h
-        return 'conv_patch_bf16_kernel<%d,%d,%d,%d,%s>' % (ci, co, h, d, 'pool8' if C3D_POOL[name] == 8 else 'pool1')
-    rows = n_windows * d * h * h
-    pool = 'pool%d' % C3D_POOL[name]
-    if dtype == 'bf16' and co % 256 == 0 and -(-rows // 256) * (co // 256) >= 1024:
-        return 'igemm_wide_kernel<256x256,%s>' % pool
-    if dtype == 'bf16' and co == 128 and -(-rows // 512) >= 1024:
-        return 'igemm_wide_kernel<512x128,%s>' % pool
-    if rows >= 65536:
-        return 'igemm_stagger_kernel<256x128,%s>' % pool
-    return 'igemm_kernel<128x128,%s>' % pool
-
-
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
 
 
@@ -77,6 +56,10 @@ def parse():
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16')
     ap.add_argument('--c3d-chunk', type=int, default=1024, help='windows per C3D launch chain')
     ap.add_argument('--graph', action='store_true', help='train workload: replay the step as HIP graphs')
+    ap.add_argument('--dp-train-probe', choices=['auto', 'on', 'off'], default='auto',
+                    help="after the headline timing also time BASELINE config 4's data-parallel training step (B=8 x T=35 per "
+                         "GPU: fwd + bwd + bucketed RCCL all-reduce + clip + Adam) and report it under 'dp_train'; auto = when "
+                         "more than one rank runs, so that the driver's N>1 command exercises the collective path")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
     ap.add_argument('--cpu-threads', type=int, default=16, help='host threads for the CPU baseline')
@@ -213,6 +196,12 @@ def main():
     else:
         assert torch.isfinite(probs).all(), 'non-finite saliency maps'
 
+    # ---- N > 1: the driver's one command must also exercise the collective path (inference has none): BASELINE config 4's
+    # training step at its per-GPU shape, after the headline timing, reported in extra keys
+    dp_train = None
+    if args.dp_train_probe == 'on' or (args.dp_train_probe == 'auto' and world > 1):
+        dp_train = rdist.dp_train_probe(dist, dev, rank=rank, batch=8, n_steps=35, steps=max(5, args.steps), warmup=2, dtype=args.dtype)
+
     if rank == 0:
         frames_total = world * F * args.steps
         value = frames_total / elapsed
@@ -221,7 +210,8 @@ def main():
             groups = {}
             for name, _, _, _, _ in C3D_LAYERS:
                 ms, calls = cprof[name]
-                grp = groups.setdefault(c3d_kernel_group(name, min(args.c3d_chunk, F), args.dtype, train=ft is not None), [0.0, 0.0, 0])
+                # the library names the kernel it launched for this layer at this chunk size (rgp_c3d_layer_kernel_name)
+                grp = groups.setdefault(c3d.layer_kernel_name(C3D_NAMES.index(name), min(args.c3d_chunk, F)), [0.0, 0.0, 0])
                 grp[0] += ms
                 grp[1] += C3D_FLOPS[name] * F * args.steps          # flops executed in the timed region
                 grp[2] += calls
@@ -240,7 +230,9 @@ def main():
         # (scripts/pmc_summary.py writes profiles/r02_traffic_dominant_kernel.json from such a run; DESIGN.md quotes it).
         traffic = None
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / peak, 4), 'traffic': traffic, 'kernel': kname,
+                    'frac': round(achieved / peak, 4), 'traffic': traffic,
+                    'traffic_profile': 'profiles/r03_pmc_summary.json (separate rocprofv3 --pmc passes of this command)',
+                    'kernel': kname,
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
                     'algorithmic_gflop_per_launch': round(flops / max(calls, 1) / 1e9, 3)}
         flops_frame = HEAD_FLOPS_FRAME + (C3D_FLOPS_FRAME if c3d is not None else 0.0)
@@ -276,6 +268,8 @@ def main():
             'stage_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in list(cprof.items()) + list(hprof.items())},
             'roofline': roofline,
         }
+        if dp_train is not None:
+            out['dp_train'] = dp_train
         if world == 1 and not args.no_cpu_baseline and args.workload in ('e2e', 'head'):
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
@@ -283,6 +277,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if dp_train is not None and (dp_train['ranks_seen'] != args.gpus or not dp_train['replicas_in_sync']):
+        raise SystemExit('bench.py: the data-parallel probe saw %d ranks for --gpus %d (replicas in sync: %s)'
+                         % (dp_train['ranks_seen'], args.gpus, dp_train['replicas_in_sync']))
 
 
 if __name__ == '__main__':

@@ -155,3 +155,71 @@ class GradBucketReducer(object):
                         bucket.div_(self.dist.get_world_size())
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self.pending = []
+
+
+def ranks_seen(dist, rank, device='cpu'):
+    """Number of distinct ranks that answer an all-gather (1 without a process group)."""
+    if dist is None:
+        return 1
+    mine = torch.tensor([int(rank)], dtype=torch.int64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return len(set(int(t.item()) for t in got))
+
+
+def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2, dtype='bf16', seed=0):
+    """BASELINE config 4 at its per-GPU shape (B = 8 clips x T = 35 per rank) as ONE data-parallel training step:
+    gaze_grcn forward + backward on the rank's own clips -> GradBucketReducer (the flat 12 MB fp32 gradient, RCCL AVG
+    on a side stream) -> finish -> clip_by_global_norm(10) + TF-Adam (base.py:286-297).  Timed like the headline
+    (barrier, `steps` steps, barrier, MAX over ranks).  Every rank starts from the same weights and sees different
+    clips, so after the steps the weights must still be identical on all ranks -- checked with a MAX/MIN all-reduce of
+    a checksum.  Returns a dict (same on every rank)."""
+    import time
+    from . import synthetic as syn
+    from .engine import GrcnEngine
+    dev = torch.device(device)
+    world = dist.get_world_size() if dist is not None else 1
+    head = GrcnEngine(batch, n_steps, dtype=dtype, save_for_backward=True, device=dev)
+    head.set_weights(syn.grcn_params(seed + 1, n_steps))
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + int(rank))
+    x = torch.relu(torch.randn(batch, n_steps, 1024, 7, 7, device=dev, generator=g))
+    gt = torch.rand(batch, n_steps, 49, 49, device=dev, generator=g) + 1e-3
+    gt = (gt / gt.sum((-1, -2), keepdim=True)).contiguous()
+    logits = torch.empty(batch, n_steps, 49, 49, device=dev)
+    probs = torch.empty_like(logits)
+    reducer = GradBucketReducer(dist, dev)
+    k = [0]
+    gnorm = [None]
+
+    def step():
+        head.forward(x, out_logits=logits, out_probs=probs)
+        head.backward(logits, probs, gt)
+        reducer.reduce(head.flat_grads)
+        reducer.finish()
+        gnorm[0] = head.adam_step(k[0], 1e-4 * 0.8 ** (k[0] // 500), max_grad_norm=10.0)
+        k[0] += 1
+
+    for _ in range(warmup):
+        step()
+    barrier(dist, dev)
+    bytes0 = reducer.bytes_reduced
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier(dist, dev)
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0, dev)
+    head.status()
+    seen = ranks_seen(dist, rank, dev)
+    # replicas stay replicas: same weights on every rank after the averaged steps
+    chk = float(head.flat_params.double().abs().sum().item())
+    hi = max_over_ranks(dist, chk, dev)
+    lo = -max_over_ranks(dist, -chk, dev)
+    return {'workload': 'gaze_grcn data-parallel TRAINING step (BASELINE config 4 per-GPU shape): fwd + bwd + bucketed '
+                        'gradient all-reduce (mean, side stream) + clip_by_global_norm(10) + TF-Adam',
+            'clips_per_gpu': batch, 'n_lstm_steps': n_steps, 'steps': steps, 'warmup': warmup, 'dtype': dtype,
+            'ms_per_step': round(elapsed / steps * 1e3, 4),
+            'frames_per_s': round(world * batch * n_steps * steps / elapsed, 1),
+            'allreduce_bytes_per_step': int((reducer.bytes_reduced - bytes0) // max(steps, 1)),
+            'backend': _backend(dist), 'ranks_seen': seen, 'world': world,
+            'grad_norm_last': float(gnorm[0].item()), 'replicas_in_sync': bool(abs(hi - lo) <= 1e-9 * max(abs(hi), 1.0))}

@@ -120,6 +120,24 @@ def grcn4_step():
 
 out['cfg4_grcn_bf16_B8_T35_train_step'] = entry(B4 * T4, timed(grcn4_step))
 del eng
+
+# the reference's own shapes: training B = 28 x T = 42 (/root/reference/models/train_gaze.py:75, gaze_rnn.py:50) and the LSMDC
+# map extraction B = 14 x T = 105 (/root/reference/models/extract_map.py:63-65), gaze_grcn head on features
+for tag, Br, Tr, train in (('ref_train_B28_T42', 28, 42, True), ('ref_extract_map_B14_T105', 14, 105, False)):
+    eng = GrcnEngine(Br, Tr, dtype='bf16', save_for_backward=train, device=dev)
+    eng.set_weights(syn.grcn_params(9, Tr))
+    xr = torch.relu(torch.randn(Br, Tr, 1024, 7, 7, device=dev, generator=g))
+    gtr = torch.rand(Br, Tr, 49, 49, device=dev, generator=g)
+    gtr = (gtr / gtr.sum((-1, -2), keepdim=True)).contiguous()
+    out['%s_grcn_bf16_head_fwd' % tag] = entry(Br * Tr, timed(lambda: eng.forward(xr)))
+    if train:
+        def ref_step():
+            lg, pr = eng.forward(xr)
+            eng.backward(lg, pr, gtr)
+            eng.adam_step(0, 1e-4)
+        out['%s_grcn_bf16_head_train_step' % tag] = entry(Br * Tr, timed(ref_step))
+    eng.status()
+    del eng, xr, gtr
 ft = EndToEndGaze(16, 16, dtype='bf16', device=dev, seed=6)
 v16 = torch.rand(256, 16, 112, 112, 3, device=dev, generator=g) - 0.5
 gt16 = torch.rand(16, 16, 49, 49, device=dev, generator=g)

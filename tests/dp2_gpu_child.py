@@ -65,7 +65,10 @@ def main():
                'param_step_agree': float(((par_dp - par_ref).abs() < 2e-5).double().mean()),
                'bytes_reduced': int(m.reducer.bytes_reduced)}
     rdist.barrier(dist, dev)
+    # bench.py's N > 1 leg (dist.dp_train_probe) under world size 2: both ranks must be seen and stay in sync
+    probe = rdist.dp_train_probe(dist, dev, rank=rank, batch=2, n_steps=3, steps=2, warmup=1)
     if rank == 0:
+        out['probe'] = probe
         print(json.dumps(out))
     dist.destroy_process_group()
 

@@ -61,6 +61,8 @@ def main():
     out['loss_after_2_steps'] = [res[0][2], res[1][2]]
     out['gnorm'] = [res[0][3], res[1][3]]
     out['bytes_reduced_per_step'] = res[1][4] // 3
+    # bench.py's N > 1 leg (dist.dp_train_probe) through RCCL with the forced one-rank group, at config 4's shape
+    out['probe'] = rdist.dp_train_probe(dist, dev, rank=0, batch=8, n_steps=35, steps=3, warmup=1)
     dist.destroy_process_group()
     print(json.dumps(out))
 

@@ -26,6 +26,9 @@ def test_rccl_one_rank_group_runs_the_reducer(gpu):
     assert abs(out['loss_after_2_steps'][0] - out['loss_after_2_steps'][1]) < 1e-2 * abs(out['loss_after_2_steps'][0]), out
     # the head's flat buffer + the eight conv layers' buckets went through RCCL every step
     assert out['bytes_reduced_per_step'] > 100e6, out
+    pr = out['probe']
+    assert pr['backend'] == 'nccl' and pr['ranks_seen'] == 1 and pr['replicas_in_sync'], pr
+    assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6 and pr['ms_per_step'] > 0 and pr['grad_norm_last'] > 0, pr
 
 
 def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
@@ -43,3 +46,6 @@ def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
     assert abs(out['gnorm_dp'] - out['gnorm_ref']) < 1e-4 * out['gnorm_ref'], out
     assert out['param_step_agree'] > 0.99, out
     assert out['bytes_reduced'] > 2 * 100e6, out                 # two steps' worth of buckets went through the group
+    pr = out['probe']
+    assert pr['world'] == 2 and pr['ranks_seen'] == 2 and pr['replicas_in_sync'], pr
+    assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6, pr
