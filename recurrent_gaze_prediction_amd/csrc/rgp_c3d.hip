@@ -48,10 +48,12 @@ template <typename T>
 int layer_dispatch(rgp_c3d* c, int i, int n, hipStream_t s) {
   constexpr int G0 = sizeof(T) == 2 ? 4 : 2;
   if (i == 0 && sizeof(T) == 2) return run_conv1a_bf16(c, n, s);
-  // conv2a ... conv4b: the patch kernels (conv_patch.hip.h, conv_patch14.hip.h); they read the filter in its chunk-major packing
+  // conv2a ... conv5b: the patch kernels (conv_patch.hip.h, conv_patch14.hip.h, conv_patch7.hip.h); they read the filter in
+  // its chunk-major packing
   if (sizeof(T) == 2 && c->use_patch() && ((i == 1 && dev_knob("RGP_C2PATCH", 1)) || (i == 3 && c->L[3].chunk_major == 64 && dev_knob("RGP_C3PATCH", 1)) ||
                                      (i == 2 && c->L[2].chunk_major == 64 && dev_knob("RGP_C3APATCH", 1)) ||
-                                     ((i == 4 || i == 5) && c->L[i].chunk_major == 64 && dev_knob("RGP_C4PATCH", 1))))
+                                     ((i == 4 || i == 5) && c->L[i].chunk_major == 64 && dev_knob("RGP_C4PATCH", 1)) ||
+                                     ((i == 6 || i == 7) && c->L[i].chunk_major == 64 && dev_knob("RGP_C5PATCH", 1))))
     return run_conv_patch_bf16(c, i, n, s);
   switch (i) {
     case 0: return run_layer<T, G0, 4>(c, i, n, s);
@@ -319,6 +321,8 @@ const char* rgp_c3d_layer_kernel_name(const rgp_c3d_t* c, int i, int n_windows) 
     snprintf(buf, sizeof(buf), "conv_patch_bf16_kernel<%d,%d,%d,%d,pool%d>", l.cin, l.cout, l.H, l.D, P);
   } else if (bf && c->use_patch() && (i == 4 || i == 5) && c->L[i].chunk_major == 64) {
     snprintf(buf, sizeof(buf), "conv_patch14_bf16_kernel<%d,pool%d>", l.cin, P);
+  } else if (bf && c->use_patch() && (i == 6 || i == 7) && c->L[i].chunk_major == 64) {
+    snprintf(buf, sizeof(buf), "conv_patch7_bf16_kernel<%s>", i == 6 ? "image" : "rows");
   } else {
     IgemmParams p = make_params(c->L[i], c->ws, c->ws, n);
     p.tile128 = c->tile128();

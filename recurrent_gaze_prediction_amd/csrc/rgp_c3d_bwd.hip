@@ -222,7 +222,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     IgemmParams p = make_params(b.dg, ws + b.dypre_off, ws, n);
     p.tile128 = c->tile128();
     if (pooled(i - 1)) {
-      if (sizeof(T) == 2 && c->use_patch() && (i == 1 || i == 2) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+      if (sizeof(T) == 2 && c->use_patch() && (i == 1 || i == 2 || i == 6) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
         RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));      // conv_patch.hip.h, dense output
       } else {
         EpiParams e = make_epi(b.dg, ws + c->dyp_off, ws);
@@ -238,7 +238,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
           (const int*)(ws + c->unpad_off[i - 1]), c->act_stride[i], (T*)(ws + lo.dypre_off), (const int*)(ws + lo.win_tab_off),
           (const int*)(ws + lo.q_off_off), lo.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, rows, grads + lo.grad_b);
       RGP_HIP(hipGetLastError());
-    } else if (sizeof(T) == 2 && c->use_patch() && (i == 3 || i == 5) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+    } else if (sizeof(T) == 2 && c->use_patch() && (i == 3 || i == 5 || i == 7) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
       RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));        // conv_patch.hip.h / conv_patch14.hip.h
     } else {
       EpiParams e = make_epi(b.dg, ws + lo.dypre_off, ws);

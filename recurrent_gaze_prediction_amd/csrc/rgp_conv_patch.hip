@@ -3,6 +3,7 @@
 #include "rgp_c3d_plan.h"
 #include "conv_patch.hip.h"
 #include "conv_patch14.hip.h"
+#include "conv_patch7.hip.h"
 
 using namespace rgp;
 
@@ -50,7 +51,30 @@ static int run_conv_patch14(rgp_c3d* c, int layer, int n, hipStream_t s) {
   return RGP_OK;
 }
 
+// conv5a (-> halo-padded act7) and conv5b (-> the conv5b rows the projection consumes), conv_patch7.hip.h
+template <int OUT>
+static int run_conv_patch7(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  ConvPatchParams p;
+  p.in = (const bf16_t*)(c->ws + c->act_off[layer]);
+  p.wp = (const bf16_t*)(c->ws + c->L[layer].w_off);
+  p.bias = c->bias[layer];
+  p.out = (bf16_t*)(c->ws + c->act_off[layer + 1]);
+  p.argmax = nullptr;
+  p.mask = nullptr;
+  p.n_windows = n;
+  p.ablate = 0;
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  auto kern = conv_patch7_bf16_kernel<OUT>;
+  RGP_TRY(ensure_dyn_smem((const void*)kern, Patch7Cfg::SMEM));
+  kern<<<n_cu, 512, Patch7Cfg::SMEM, s>>>(p);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
+  if (layer == 6) return run_conv_patch7<0>(c, layer, n, s);
+  if (layer == 7) return run_conv_patch7<1>(c, layer, n, s);
   if (layer == 4) return run_conv_patch14<256, false, false>(c, layer, n, s);
   if (layer == 5) return c->save ? run_conv_patch14<512, true, true>(c, layer, n, s) : run_conv_patch14<512, true, false>(c, layer, n, s);
   if (layer == 1) return c->save ? run_conv_patch<64, 128, 56, 16, true, true>(c, layer, n, s) : run_conv_patch<64, 128, 56, 16, true, false>(c, layer, n, s);
@@ -59,8 +83,9 @@ int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   return set_err(RGP_EINVAL, "conv_patch: no kernel for layer %d", layer);
 }
 
-// input gradients (bf16): the un-pooled patch kernels on dY with the backward plan's rotated filter.  conv3b / conv4b:
-// masked by the forward activation, written as dY of conv3a / conv4a; conv2a / conv3a: dense, for the un-pool kernel
+// input gradients (bf16): the un-pooled patch kernels on dY with the backward plan's rotated filter.  conv3b / conv4b /
+// conv5b: masked by the forward activation, written as dY of conv3a / conv4a / conv5a; conv2a / conv3a / conv5a: dense,
+// for the un-pool kernel
 int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   ConvPatchParams p;
   p.in = (const bf16_t*)(c->ws + c->B[layer].dypre_off);
@@ -98,6 +123,16 @@ int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
     constexpr int smem = Patch14Cfg<512, false>::SMEM;
     RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
     kern<<<n_cu, 512, smem, s>>>(p);
+  } else if (layer == 7) {                                   // conv5b: masked by conv5a's activation, written as dY of conv5a
+    auto kern = conv_patch7_bf16_kernel<0, true>;
+    RGP_TRY(ensure_dyn_smem((const void*)kern, Patch7Cfg::SMEM));
+    kern<<<n_cu, 512, Patch7Cfg::SMEM, s>>>(p);
+  } else if (layer == 6) {                                   // conv5a: dense [n][98][512] for the un-pool kernel (pool4)
+    p.out = (bf16_t*)(c->ws + c->dyp_off);
+    p.mask = nullptr;
+    auto kern = conv_patch7_bf16_kernel<2, true>;
+    RGP_TRY(ensure_dyn_smem((const void*)kern, Patch7Cfg::SMEM));
+    kern<<<n_cu, 512, Patch7Cfg::SMEM, s>>>(p);
   } else {
     return set_err(RGP_EINVAL, "conv_patch dgrad: no kernel for layer %d", layer);
   }

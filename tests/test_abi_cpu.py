@@ -84,14 +84,14 @@ def test_c3d_kernel_names_and_flags_host_only():
     assert d[1] == 'conv_patch_bf16_kernel<64,128,56,16,pool8>' and d[2] == 'conv_patch_bf16_kernel<128,256,28,8,pool1>'
     assert d[3] == 'conv_patch_bf16_kernel<256,256,28,8,pool8>'
     assert d[4] == 'conv_patch14_bf16_kernel<256,pool1>' and d[5] == 'conv_patch14_bf16_kernel<512,pool8>'
-    assert d[6] == d[7] == 'igemm_stagger_kernel<256x128,bf16,pool1>'
+    assert d[6] == 'conv_patch7_bf16_kernel<image>' and d[7] == 'conv_patch7_bf16_kernel<rows>'
     g = names(_lib.RGP_C3D_KERNELS_IGEMM, 1024)
     assert g[1] == 'igemm_wide_kernel<512x128,bf16,pool8>' and g[3] == 'igemm_wide_kernel<256x256,bf16,pool8>'
-    assert g[4] == 'igemm_wide_kernel<256x256,bf16,pool1>' and g[6] == d[6]
+    assert g[4] == 'igemm_wide_kernel<256x256,bf16,pool1>' and g[6] == g[7] == 'igemm_stagger_kernel<256x128,bf16,pool1>'
     t = names(_lib.RGP_C3D_KERNELS_IGEMM | _lib.RGP_C3D_KERNELS_TILE128, 1024)
     assert all(x.startswith('igemm_kernel<128x128,bf16') for x in t[1:])
     small = names(0, 2, max_windows=2)
-    assert small[1].startswith('conv_patch_bf16_kernel') and small[6] == 'igemm_kernel<64x64,bf16,pool1>'
+    assert small[1].startswith('conv_patch_bf16_kernel') and small[6] == 'conv_patch7_bf16_kernel<image>'
     f32 = names(0, 1024, dtype=_lib.RGP_F32)
     assert f32[0] == 'igemm_kernel<128x64,f32,pool4>' and f32[3] == 'igemm_stagger_kernel<256x128,f32,pool8>'
     h = ctypes.c_void_p()
