@@ -347,16 +347,19 @@ template <int P> __device__ __forceinline__ void pool_window_argmax(const float*
   *(uint2*)amax = make_uint2(lo, hi);
 }
 
-template <int BM, int BN> struct IgemmSmem {
+template <int BM, int BN, int NS = 2> struct IgemmSmem {
   static constexpr int TILE_BYTES = (BM + BN) * 128;
-  static constexpr int ROWINFO_OFF = 2 * TILE_BYTES;
+  static constexpr int ROWINFO_OFF = NS * TILE_BYTES;
   static constexpr int BYTES = ROWINFO_OFF + BM * 24;   // int64 rowin + int img + int ml + int64 rowout per row
 };
 
 // G = K-subchunks per 128-byte chunk that carry their own tap offset (1 for
 // Cin*sizeof(T) >= 128 B; 2/4 when a 128-B chunk spans several taps).
 // P = rows per pooling window (1, 4 or 8), rows of a window are consecutive in m.
-template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
+// NS = LDS stages of the K loop.  2: double buffer, every K-tile waits for its successor's DMA (fine while a tile's MFMAs
+// outlast the DMA latency).  NS > 2: a ring with NS - 2 tiles in flight behind a counted vmcnt, for the skinny GEMMs
+// (64 x 16 tiles: 8 MFMAs per wave and K-tile, far less than one L2 / Infinity-Cache round trip).
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p, const EpiParams e) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   static_assert(WTM % P == 0, "pool window inside a slab");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  long long* s_rowin = (long long*)(smem + IgemmSmem<BM, BN>::ROWINFO_OFF);
+  long long* s_rowin = (long long*)(smem + IgemmSmem<BM, BN, NS>::ROWINFO_OFF);
   int* s_rowimg = (int*)(s_rowin + BM);
   int* s_rowml = s_rowimg + BM;
   long long* s_rowout = (long long*)(s_rowml + BM);   // output offset of the row's pooling window, resolved here
@@ -463,9 +466,20 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fk = lane >> 4;
+  f32x4 acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};      // skinny tiles (one MFMA tile per wave): second accumulation chain
   auto compute = [&](int buf) {
     const char* abuf = smem + buf * TILE_BYTES + (wm * WTM + frow) * 128;
     const char* bbuf = smem + buf * TILE_BYTES + BM * 128 + (wn * WTN + frow) * 128;
+    if constexpr (MI == 1 && NI == 1) {
+      // a single 16 x 16 tile per wave: the K-tile's fragments are read up front and its two halves run on two
+      // accumulators -- one dependent MFMA chain of 8 with an LDS round trip in the middle otherwise
+      const int pc0 = ((fk) ^ (frow & 7)) * 16, pc1 = ((4 + fk) ^ (frow & 7)) * 16;
+      const f32x4 a0 = *(const f32x4*)(abuf + pc0), b0 = *(const f32x4*)(bbuf + pc0);
+      const f32x4 a1 = *(const f32x4*)(abuf + pc1), b1 = *(const f32x4*)(bbuf + pc1);
+      Mma<T>::step(acc[0][0], a0, b0);
+      Mma<T>::step(acc_b, a1, b1);
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int pc = ((s * 4 + fk) ^ (frow & 7)) * 16;
@@ -481,6 +495,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     }
   };
 
+  if constexpr (NS == 2) {
   stage(0, kt_begin, ko_first);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -498,7 +513,45 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     __syncthreads();
     cur ^= 1;
   }
+  } else {
+    // ring of NS slots: tiles kt+1 .. kt+NS-2 are in flight while tile kt is multiplied.  The slot refilled in iteration
+    // kt (with tile kt+NS-1) is the one multiplied in iteration kt-1: its DMA is issued behind the barrier that every wave
+    // reaches after that compute.
+    static_assert(G == 1 && NS >= 3 && NS <= 8, "ring variant: plain K schedule");
+    constexpr int IPW_FULL = A_PER_WAVE + B_PER_WAVE;          // DMA instructions per stage of a wave that also stages B
+    // the K-offset table through the SCALAR cache (constant address space): a vector load here would sit in the vmcnt
+    // queue the counted waits below are written for, and the compiler would drain the ring to consume it
+    auto load_koff_s = [&](int kt) -> int {
+      kt = kt < p.nk ? kt : p.nk - 1;
+      return ((const __attribute__((address_space(4))) int*)p.koff)[kt];
+    };
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+      if (kt_begin + u < kt_end) stage(u, kt_begin + u, load_koff_s(kt_begin + u));
+    int ko_ring = load_koff_s(kt_begin + NS - 1);
+    int slot = 0, fill = NS - 1;
+#pragma clang loop unroll(disable)
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      // tile kt landed: younger are the NS - 2 tiles issued after it (the last NS - 2 iterations simply drain)
+      if (kt + NS - 2 < kt_end) {
+        if (b_active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW_FULL * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PER_WAVE * (NS - 2)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (kt + NS - 1 < kt_end) {
+        stage(fill, kt + NS - 1, ko_ring);
+        ko_ring = load_koff_s(kt + NS);
+      }
+      compute(slot);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    __syncthreads();                                            // staging below reuses the tile buffers
+  }
 
+  if constexpr (MI == 1 && NI == 1) acc[0][0] += acc_b;
   // ---- epilogue: one wave-row slab (WTM rows x BN cols, fp32) at a time ----
   constexpr int LDS_LD = BN + 4;
   float* stg = (float*)smem;

@@ -223,10 +223,10 @@ struct PackBatch {
 };
 
 // ---- launch dispatch -------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi, int NS = 2>
 int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi>;
-  constexpr int smem = IgemmSmem<BM, BN>::BYTES;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi, NS>;
+  constexpr int smem = IgemmSmem<BM, BN, NS>::BYTES;
   RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
   const int n_mt = (p.M + BM - 1) / BM, n_nt = (p.N + BN - 1) / BN;
   kern<<<dim3(n_mt * n_nt, ksplit), dim3(WM * WN * 64), smem, s>>>(p, e);
@@ -276,7 +276,7 @@ int launch_wide(const IgemmParams& p, const EpiParams& e, hipStream_t s) {
 // Tile choice by problem size and output width.  The persistent 256-row kernels (igemm_wide.hip.h, igemm_stagger.hip.h)
 // need about a thousand tiles; below that 128x128 (2x2 waves of 64x64) for N >= 128, 128x64 (2x2 waves of 64x32) for N
 // in (32, 64], 128x32 (4x1 waves of 32x32) below, and 64x64 for the latency-bound recurrent convs.
-enum IgemmTile { TILE_WIDE_256x256, TILE_WIDE_512x128, TILE_STAGGER_256x128, TILE_LOOP_256x128, TILE_64x64, TILE_128x128, TILE_128x64, TILE_128x32 };
+enum IgemmTile { TILE_WIDE_256x256, TILE_WIDE_512x128, TILE_STAGGER_256x128, TILE_LOOP_256x128, TILE_64x16, TILE_64x64, TILE_128x128, TILE_128x64, TILE_128x32 };
 
 template <typename T, int G, int P, class Epi>
 IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
@@ -295,6 +295,12 @@ IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
   }
   if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX && p.M >= 256 * 256) return TILE_STAGGER_256x128;
   if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return TILE_LOOP_256x128;
+  // one row tile and a wide output (the fc-GRU's recurrent GEMMs: M = B <= 64 rows, N = 1624 / 3248, K = 1624): even
+  // 64x64 tiles give only 26 / 51 blocks, each bound by ONE CU's MFMA rate (40 us per launch, 32 launches per forward);
+  // 64x16 tiles (4 waves of 16x16) spread the same FLOPs over 102 / 203 CUs
+  if constexpr (G == 1 && P == 1) {
+    if (ksplit == 1 && p.M <= 64 && p.N >= 512 && (p.N + 63) / 64 < 128) return TILE_64x16;
+  }
   // latency-bound problems (the per-timestep recurrent convs: M = B*49): 64x64 tiles give 4x the
   // blocks of 128x128, so more of the 256 CUs have a tile
   {
@@ -312,6 +318,7 @@ inline const char* igemm_tile_name(IgemmTile t) {
     case TILE_WIDE_512x128: return "igemm_wide_kernel<512x128";
     case TILE_STAGGER_256x128: return "igemm_stagger_kernel<256x128";
     case TILE_LOOP_256x128: return "igemm_kernel<256x128";
+    case TILE_64x16: return "igemm_kernel<64x16";
     case TILE_64x64: return "igemm_kernel<64x64";
     case TILE_128x128: return "igemm_kernel<128x128";
     case TILE_128x64: return "igemm_kernel<128x64";
@@ -355,6 +362,9 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
     }
 #endif
     return launch_stagger<T, P, Epi>(p, e, s);
+  }
+  if constexpr (G == 1 && P == 1) {
+    if (tile == TILE_64x16) return launch_cfg<T, 64, 16, 4, 1, G, P, Epi, 8>(p, e, s, ksplit);
   }
   switch (tile) {
 #ifdef RGP_DEV_KNOBS
