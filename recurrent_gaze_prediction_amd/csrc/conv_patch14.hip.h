@@ -3,17 +3,27 @@
 // Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:174-240 (conv4a, conv4b, pool4).
 //
 // What differs from conv_patch.hip.h (read that header first):
-//  * 7 pooling windows per pooled row: an m-tile pairs the windows (row r, xp) and (row r + 1, xp) VERTICALLY, a wave
-//    owns two consecutive pooled rows x 7 columns (14 windows = 7 m-tiles), and "consecutive" runs through the 14 pooled
-//    rows of a clip window (2 pooled planes x 7): the pair (6, 7) straddles the two pooled planes.  A block tile is two
-//    such wave tiles (waves 2 (M) x 4 (N): 224 positions x 256 channels) and may straddle two clip windows; the 512
+//  * 7 pooling windows per pooled row.  Every POOLED ROW is a slot of its own in the LDS patch: 4 input planes x 4 input
+//    rows x 16 pixels, fetched row by row (one LDS-DMA instruction = one 16-pixel row of one channel slice = 1 KB) -- rows
+//    shared by neighbouring pooled rows are fetched twice, 64 KB per 27 K steps against the 432 KB of filter slabs.  A
+//    block tile is 4 consecutive slots = 28 pooling windows = 224 positions x 256 channels (waves 2 (M) x 4 (N)); the 512
 //    output channels are two column tiles that follow each other in the tile order (the second finds the patch in L2).
-//  * so every POOLED ROW is a slot of its own in the LDS patch: 4 input planes x 4 input rows x 16 pixels, fetched row by
-//    row (one LDS-DMA instruction = one 16-pixel row of one channel slice = 1 KB) -- rows shared by neighbouring pooled
-//    rows are fetched twice, 64 KB per 27 K steps against the 432 KB of filter slabs.  LDS rows have a pitch of 1152 B
-//    (= 128 mod 256) and the plane buffers start at 32 (k & 1): the bank argument of conv_patch.hip.h holds per window
-//    (its 2 x 2 pixels of a plane fall in the four 64-byte quarters of a bank row), whatever the two windows of an
-//    m-tile are.
+//    Slots are numbered (pooled plane zp, clip window, pooled row yp), so that a block tile lies in ONE pooled plane
+//    (one tile of the launch straddles the two).
+//  * fragments are dz-PURE: a 16-row m-tile is 4 pooling windows x (dy, dx) of one output plane z = 2 zp + dz.  The depth
+//    is 4 with padding 1, so output plane z = 0 multiplies its kz = 0 taps with the zero halo plane z = -1, and z = 3 its
+//    kz = 2 taps with the halo plane z = 4: in a tile of pooled plane 0 the dz = 0 fragments skip the kz = 0 tap group, in
+//    a tile of pooled plane 1 the dz = 1 fragments skip kz = 2 -- a sixth of the dense MFMA work, products with structural
+//    zeros, is not issued (rates are still quoted against the dense 27-tap FLOP count).  Each M wave holds 4 fragments of
+//    one dz and 3 of the other (wave 0: dz 0 f 0..3 + dz 1 f 0..2; wave 1: dz 1 f 3..6 + dz 0 f 4..6), so both waves of a
+//    SIMD shrink in the same K steps (12 / 16 MFMAs instead of 28) and the pair stays balanced.
+//  * banks: LDS rows have a pitch of 1152 B (= 128 mod 256: the 2 x 2 pixels of a window fall in the four 64-byte
+//    quarters of a 256-byte bank row) and the rows of the ODD slots start 32 bytes late; a fragment takes two windows from
+//    even slots (rows 0-7) and two from odd slots (rows 8-15), which puts the 16 lanes of every ds_read_b128 group on 16
+//    different 16-byte slots for every tap (scripts/check_conv14_banks.py enumerates them).
+//  * pooling: max over (dy, dx) in the lane's four accumulator registers, max over dz between two fragments of the same
+//    wave -- except fragment 3, whose dz = 0 half lives in M wave 0 and dz = 1 half in M wave 1: wave 1 passes its fp32
+//    maxima (and arg-max indices) through the filter-ring slot that is idle during the epilogue.
 #pragma once
 #include <type_traits>
 
@@ -65,12 +75,12 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
   const int wm = wave >> 2, wn = wave & 3;
   const bool group_b = wave >= 4;
   const int frow = lane & 15, fk = lane >> 4;
-  auto plane_base = [](int k) { return (unsigned)(k * C::PLANE_STRIDE + 32 * (k & 1)); };
+  auto plane_base = [](int k) { return (unsigned)(k * C::PLANE_STRIDE); };
 
-  // tiles: (block tile b = wave tiles 2b, 2b+1 of the 7 n_windows, column tile ct), ct innermost; dealt to the XCDs in
+  // tiles: (block tile b = slots 4b .. 4b+3 of the 14 n_windows, column tile ct), ct innermost; dealt to the XCDs in
   // contiguous ranges
-  const int n_wt = 7 * p.n_windows;                          // wave tiles (pairs of pooled rows)
-  const int nt = ((n_wt + 1) >> 1) * C::NCT;
+  const int n_slots = 14 * p.n_windows;                      // pooled rows, numbered (zp, clip window, yp)
+  const int nt = ((n_slots + 3) >> 2) * C::NCT;
   auto tile_of = [&](int t) {
     const int q = nt >> 3, r = nt & 7, x = t & 7, y = t >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
@@ -78,18 +88,24 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
   int t_seq = blockIdx.x;
   if (t_seq >= nt) return;
 
-  // pooled row of slot u (0 .. 3) of block tile b: wave tile 2b + (u >> 1), row 2 j + (u & 1) of the clip's 14
+  // pooled row of slot u (0 .. 3) of block tile b
   struct Slot { int n, zp, yp; bool valid; };
   auto slot_of = [&](int b, int u) {
     Slot s;
-    int g = 2 * b + (u >> 1);
-    s.valid = g < n_wt;
-    if (!s.valid) g = n_wt - 1;
-    s.n = g / 7;
-    const int r = 2 * (g - s.n * 7) + (u & 1);
-    s.zp = r >= 7 ? 1 : 0;
-    s.yp = r - 7 * s.zp;
+    int g = 4 * b + u;
+    s.valid = g < n_slots;
+    if (!s.valid) g = n_slots - 1;
+    s.zp = g >= 7 * p.n_windows ? 1 : 0;
+    const int r = g - s.zp * 7 * p.n_windows;
+    s.n = r / 7;
+    s.yp = r - s.n * 7;
     return s;
+  };
+  // window w (0 .. 3) of fragment f (0 .. 6): two windows of the even slots, two of the odd slots -> (slot u, column xp)
+  auto frag_window = [](int f, int w, int& u, int& xp) {
+    const int j = 2 * f + (w & 1);
+    u = 2 * (j / 7) + (w >> 1);
+    xp = j - 7 * (j / 7);
   };
   // the two input rows (of plane k, channel sweep cc) this wave fetches for a tile: slot wave >> 1, rows 2 (wave & 1), +1
   const int dpix = lane >> 2, dchk = lane & 3;
@@ -98,48 +114,53 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
     return (const char*)(p.in + (long long)s.n * C::IN_IMG + (long long)(2 * s.zp + k) * C::IN_PLANE + (2 * s.yp + 2 * (wave & 1)) * C::IN_ROW +
                          cc * 32);
   };
+  // (src is a wave-uniform base; the lane's part is one 32-bit offset, so no 64-bit pointer lives in vector registers)
+  const unsigned dlane = (unsigned)(dpix * (CIN * 2) + dchk * 16);
   auto dma_plane = [&](const char* src, int k, bool last_touch = false) {
     if (last_touch) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u * 16 + dpix) * (CIN * 2) + dchk * 16),
-                                         (__attribute__((address_space(3))) void*)(cq_smem + plane_base(k) + ((wave >> 1) * 4 + 2 * (wave & 1) + u) * C::LROW),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 16 * (CIN * 2) + dlane),
+                                         (__attribute__((address_space(3))) void*)(cq_smem + plane_base(k) + ((wave >> 1) * 4 + 2 * (wave & 1) + u) * C::LROW + 32 * ((wave >> 1) & 1)),
                                          16, 0, 2 /* nt */);
       return;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u * 16 + dpix) * (CIN * 2) + dchk * 16),
-                                       (__attribute__((address_space(3))) void*)(cq_smem + plane_base(k) + ((wave >> 1) * 4 + 2 * (wave & 1) + u) * C::LROW),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * 16 * (CIN * 2) + dlane),
+                                       (__attribute__((address_space(3))) void*)(cq_smem + plane_base(k) + ((wave >> 1) * 4 + 2 * (wave & 1) + u) * C::LROW + 32 * ((wave >> 1) & 1)),
                                        16, 0, RGP_PLANE_AUX);
   };
   // filter slab (conv_patch.hip.h), rows of column tile ct
   const int brow = lane >> 2;
   const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
   auto b_row = [&](int blk) { return POOL ? blk * 16 + brow : (blk >> 2) * 64 + brow * 4 + (blk & 3); };
-  const char* b_src[2];
+  unsigned b_off[2];                                          // this lane's byte offset inside the packed filter (< 2^31)
 #pragma unroll
-  for (int u = 0; u < 2; ++u) b_src[u] = (const char*)(p.wp + (long long)b_row(wave * 2 + u) * C::K) + bchk * 16;
+  for (int u = 0; u < 2; ++u) b_off[u] = (unsigned)(b_row(wave * 2 + u) * (C::K * 2) + bchk * 16);
   auto dma_b = [&](int slot, int ct, int cc, int tap) {
-    const long long koff = (long long)ct * C::TN * C::K * 2 + (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2;
+    const char* base = (const char*)p.wp + ((long long)ct * C::TN * C::K * 2 + (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2);
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[u] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + b_off[u]),
                                        (__attribute__((address_space(3))) void*)(cq_smem + C::BRING_OFF + slot * C::BSLOT + (wave * 2 + u) * 1024), 16, 0, 0);
   };
 
-  // fragment addressing: m-tile i = column xp = i; row frow of it: window (slot 2 wm + (frow >> 3)), dz, dy, dx; K chunk fk
-  const int r_ws = frow >> 3, r_dz = (frow >> 2) & 1, r_dy = (frow >> 1) & 1, r_dx = frow & 1;
-  unsigned rowaddr[7];
+  // fragment addressing.  Accumulator slot i of M wave wm: i < 4 -> (dz = wm, fragment f = 3 wm + i), i >= 4 -> (dz = 1 - wm,
+  // f = i - 4 + 4 wm); row frow of a fragment: window frow >> 2, (dy, dx) = ((frow >> 1) & 1, frow & 1); K chunk fk
+  auto frag_of = [&](int i) { return i < 4 ? 3 * wm + i : i - 4 + 4 * wm; };
+  const int r_dy = (frow >> 1) & 1, r_dx = frow & 1;
+  // ra[i]: LDS address of this lane's row of slot i in the plane its dz reads for the CURRENT tap group (kz + dz);
+  // advanced in place by one plane per tap group and taken back by two at the end of a sweep
+  unsigned ra[7];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) rowaddr[i] = lds0 + ((2 * wm + r_ws) * 4 + r_dy) * C::LROW + (2 * i + r_dx) * 64 + fk * 16;
+  for (int i = 0; i < 7; ++i) {
+    int u, xp;
+    frag_window(frag_of(i), frow >> 2, u, xp);
+    ra[i] = lds0 + (u * 4 + r_dy) * C::LROW + 32 * (u & 1) + (2 * xp + r_dx) * 64 + fk * 16 + plane_base(i < 4 ? wm : 1 - wm);
+  }
   const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
   const int cg = tid % C::CGN;
-  float b4ct[C::NCT][4];
-#pragma unroll
-  for (int t = 0; t < C::NCT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b4ct[t][q] = DGRAD ? 0.f : p.bias[t * C::TN + (POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q)];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- prologue (once) ----
@@ -160,10 +181,6 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
     const bool has_next = t_next < nt;
     const int tile_next = has_next ? tile_of(t_next) : tile;
     const int ct = tile % C::NCT, ct_next = tile_next % C::NCT;
-    float b4[4];                                              // bias of this lane's 4 MFMA columns in this column tile
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b4[q] = ct ? b4ct[1][q] : b4ct[0][q];
-
     f32x4 acc[7][4];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
@@ -171,12 +188,10 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (group_b) __builtin_amdgcn_s_barrier();               // run one half-step behind group A
 
-    auto tap_group = [&](auto NPL_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb, bool last_touch = false) {
-      constexpr int NPL = decltype(NPL_)::value;
-      unsigned ra[7];
-      const unsigned pb = r_dz ? plane_base(kz + 1) : plane_base(kz);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) ra[i] = rowaddr[i] + pb;
+    // MODE 0: all 7 fragments; 1: only slots 4 .. 6 (the first four multiply a halo plane in this tap group); 2: only 0 .. 3
+    auto tap_group = [&](auto NPL_, auto MODE_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb, bool last_touch) {
+      constexpr int NPL = decltype(NPL_)::value, MODE = decltype(MODE_)::value;
+      constexpr int I0 = MODE == 1 ? 4 : 0, I1 = MODE == 2 ? 4 : 7;
       const int s0 = cc * 27 + kz * 9;
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
@@ -188,7 +203,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
           constexpr int t = decltype(T9)::value;
           constexpr int imm = (t / 3) * C::LROW + (t % 3) * 64;
 #pragma unroll
-          for (int i = 0; i < 7; ++i) af[i] = cp_lds_read128<imm>(ra[i]);
+          for (int i = I0; i < I1; ++i) af[i] = cp_lds_read128<imm>(ra[i]);
         };
         switch (t9) {
           case 0: reads(std::integral_constant<int, 0>{}); break;
@@ -224,7 +239,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         if (t9 < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C::BPW + NPL * C::PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C::BPW) : "memory");
 #pragma unroll
-        for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(af[i]));
+        for (int i = I0; i < I1; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bf[j]));
         __builtin_amdgcn_sched_barrier(0);
@@ -232,26 +247,34 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- COMPUTE ----------------
         __builtin_amdgcn_s_setprio(1);
-#if RGP_MMA_ORDER == 1
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 7; ++i) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
-#else
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
-#endif
+          for (int i = I0; i < I1; ++i) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
       }
+      // next tap group: one plane further (after kz = 2: back to the planes of kz = 0)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) ra[i] += kz == 2 ? (unsigned)(-2 * C::PLANE_STRIDE) : (unsigned)C::PLANE_STRIDE;
     };
+    using I0_ = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
+    // pooled plane of the tile (-1: its slots straddle the two planes or the tile is ragged -- nothing is skipped) and
+    // this wave's skip mode in the kz = 0 / kz = 2 tap groups: its dz = 0 fragments are slots 0 .. 3 of M wave 0 and
+    // 4 .. 6 of M wave 1
+    const int bt = tile / C::NCT;
+    int zpu;
+    {
+      const Slot a0 = slot_of(bt, 0), a3 = slot_of(bt, 3);
+      zpu = (a3.valid && a0.zp == a3.zp) ? a0.zp : -1;
+    }
+    const int mode_k0 = zpu == 0 ? (wm == 0 ? 1 : 2) : 0;     // kz = 0 on pooled plane 0: the dz = 0 slots are idle
+    const int mode_k2 = zpu == 1 ? (wm == 0 ? 2 : 1) : 0;     // kz = 2 on pooled plane 1: the dz = 1 slots are idle
 #pragma clang loop unroll(disable)
     for (int cc = 0; cc < C::NCC; ++cc) {
       const bool last = cc == C::NCC - 1;
@@ -261,42 +284,88 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
       // column tile of a block tile; conv4a -0.4 %, conv4b -0.7 %; the input gradient was not measured and stays without
       const bool lt = !DGRAD && (cc & 1) != 0 && tile % C::NCT == C::NCT - 1;
       const bool nlt = !DGRAD && (ncc & 1) != 0 && ntile % C::NCT == C::NCT - 1;
-      tap_group(I2{}, cc, 0, plane_src(tile, cc, 2), 2, plane_src(tile, cc, 3), 3, lt);
-      tap_group(I1{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0, nlt);
-      tap_group(I1{}, cc, 2, plane_src(ntile, ncc, 1), 1, nullptr, 0, nlt);
+      const char* p2 = plane_src(tile, cc, 2);
+      const char* p3 = plane_src(tile, cc, 3);
+      if (mode_k0 == 0) tap_group(I2{}, I0_{}, cc, 0, p2, 2, p3, 3, lt);
+      else if (mode_k0 == 1) tap_group(I2{}, I1{}, cc, 0, p2, 2, p3, 3, lt);
+      else tap_group(I2{}, I2{}, cc, 0, p2, 2, p3, 3, lt);
+      tap_group(I1{}, I0_{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0, nlt);
+      const char* n1 = plane_src(ntile, ncc, 1);
+      if (mode_k2 == 0) tap_group(I1{}, I0_{}, cc, 2, n1, 1, nullptr, 0, nlt);
+      else if (mode_k2 == 1) tap_group(I1{}, I1{}, cc, 2, n1, 1, nullptr, 0, nlt);
+      else tap_group(I1{}, I2{}, cc, 2, n1, 1, nullptr, 0, nlt);
     }
     if (!group_b) __builtin_amdgcn_s_barrier();               // the groups are level again
 
-    const int bt = tile / C::NCT;
+    // bias of this lane's 4 MFMA columns in this column tile: fetched here (the wait for it also drains the 3 look-ahead
+    // slabs, once per tile) rather than held in 8 registers through the K loop
+    float b4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b4[q] = DGRAD ? 0.f : p.bias[ct * C::TN + (POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q)];
     if constexpr (POOL) {
-      // ---- epilogue: pool in registers, bias + ReLU, pooled bf16 tile (and arg-max codes) through LDS ----
+      // ---- epilogue: pool in registers -- max over (dy, dx) = the four registers, max over dz = two accumulator slots of
+      // this wave (fragment 3: one slot here, one in the other M wave, exchanged in fp32 through the idle ring slot) --
+      // then bias + ReLU, pooled bf16 tile (and arg-max codes dz 4 + dy 2 + dx, first maximum) through LDS ----
       bf16_t* stg = (bf16_t*)(cq_smem + C::STG_OFF);
       unsigned char* stga = (unsigned char*)(cq_smem + C::STGA_OFF);
+      float* xm = (float*)(cq_smem + C::BRING_OFF + ((slot + C::AHEAD) & (C::NSLOT - 1)) * C::BSLOT);   // idle until the next LOAD phase
+      unsigned char* xi = (unsigned char*)(xm + 4 * 256);
+      float m[7][4];
+      int mi[7][4];
 #pragma unroll
       for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 c = acc[i][j];
-          const int so = ((2 * wm + (fk >> 1)) * 7 + i) * C::STG_LD + wn * 64 + j * 16 + frow;      // window = slot * 7 + xp
-          if constexpr (ARGMAX) {
-            float best = c[0];
-            int idx = 0;
-            if (c[1] > best) { best = c[1]; idx = 1; }
-            if (c[2] > best) { best = c[2]; idx = 2; }
-            if (c[3] > best) { best = c[3]; idx = 3; }
-            const float ob = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, best), 0x401F));   // lane ^ 16
-            const int oi = __builtin_amdgcn_ds_swizzle(idx, 0x401F);
-            if ((fk & 1) == 0) {
-              stg[so] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
-              stga[so] = (unsigned char)(ob > best ? oi + 4 : idx);
-            }
-          } else {
-            const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
-            const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-            if ((fk & 1) == 0) stg[so] = f2bf(fmaxf(fmaxf(x, y) + b4[j], 0.f));
-          }
+          float best = c[0];
+          int idx = 0;
+          if (c[1] > best) { best = c[1]; idx = 1; }
+          if (c[2] > best) { best = c[2]; idx = 2; }
+          if (c[3] > best) { best = c[3]; idx = 3; }
+          m[i][j] = best;
+          mi[i][j] = idx;
         }
+      // staging position of (fragment f, this lane's window fk, column j 16 + frow)
+      auto stage_pos = [&](int f, int j) {
+        int u, xp;
+        frag_window(f, fk, u, xp);
+        return (u * 7 + xp) * C::STG_LD + wn * 64 + j * 16 + frow;
+      };
+      auto put = [&](int f, int j, float v0, int i0, float v1, int i1) {      // v0: dz = 0 maximum, v1: dz = 1
+        const int so = stage_pos(f, j);
+        const bool hi = v1 > v0;
+        stg[so] = f2bf(fmaxf((hi ? v1 : v0) + b4[j], 0.f));
+        if constexpr (ARGMAX) stga[so] = (unsigned char)(hi ? i1 + 4 : i0);
+      };
+      if (wm == 0) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) put(f, j, m[f][j], mi[f][j], m[f + 4][j], mi[f + 4][j]);
+      } else {
+#pragma unroll
+        for (int f = 4; f < 7; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) put(f, j, m[f][j], mi[f][j], m[f - 3][j], mi[f - 3][j]);
+        // dz = 1 half of fragment 3 (slot 0 here) for M wave 0: [window fk][column] fp32 + index byte
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xm[fk * 256 + wn * 64 + j * 16 + frow] = m[0][j];
+          if constexpr (ARGMAX) xi[fk * 256 + wn * 64 + j * 16 + frow] = (unsigned char)mi[0][j];
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
+      __builtin_amdgcn_s_barrier();
+      if (wm == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v1 = xm[fk * 256 + wn * 64 + j * 16 + frow];
+          int i1 = 0;
+          if constexpr (ARGMAX) i1 = xi[fk * 256 + wn * 64 + j * 16 + frow];
+          put(3, j, m[3][j], mi[3][j], v1, i1);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -315,22 +384,25 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         }
       }
     } else {
-      // ---- epilogue: bias + ReLU, 8-byte stores from registers (conv_patch.hip.h); this lane's window: slot
-      // 2 wm + (fk >> 1), column i; dz = fk & 1; register e: dy = e >> 1, dx = e & 1 ----
-      const Slot sl = slot_of(bt, 2 * wm + (fk >> 1));
-      if (sl.valid) {
-        const long long ow = (long long)sl.n * C::OUT_IMG + (2 * sl.zp + (fk & 1) + 1) * C::OUT_PLANE + (2 * sl.yp + 1) * C::OUT_ROW + C::NOUT + ct * C::TN +
-                             wn * 64 + frow * 4;
+      // ---- epilogue: bias + ReLU, 8-byte stores from registers (conv_patch.hip.h).  Accumulator slot i, register e: window
+      // fk of fragment frag_of(i), dz of the slot, dy = e >> 1, dx = e & 1; channels ct 256 + 64 wn + 4 frow + 0 .. 3 ----
 #pragma unroll
-        for (int i = 0; i < 7; ++i)
+      for (int i = 0; i < 7; ++i) {
+        int u, xp;
+        frag_window(frag_of(i), fk, u, xp);
+        const Slot sl = slot_of(bt, u);
+        const int dz = i < 4 ? wm : 1 - wm;
+        if (sl.valid) {
+          const long long ow = (long long)sl.n * C::OUT_IMG + (2 * sl.zp + dz + 1) * C::OUT_PLANE + (2 * sl.yp + 1) * C::OUT_ROW + (2 * xp + 1) * C::NOUT +
+                               ct * C::TN + wn * 64 + frow * 4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const long long oe = ow + (e >> 1) * C::OUT_ROW + (2 * i + (e & 1)) * C::NOUT;
+            const long long oe = ow + (e >> 1) * C::OUT_ROW + (e & 1) * C::NOUT;
             uint2 o;
             if constexpr (DGRAD) {
-              const uint2 m = *(const uint2*)(p.mask + oe);
-              const float v0 = bf2f((bf16_t)(m.x & 0xffffu)) > 0.f ? acc[i][0][e] : 0.f, v1 = bf2f((bf16_t)(m.x >> 16)) > 0.f ? acc[i][1][e] : 0.f;
-              const float v2 = bf2f((bf16_t)(m.y & 0xffffu)) > 0.f ? acc[i][2][e] : 0.f, v3 = bf2f((bf16_t)(m.y >> 16)) > 0.f ? acc[i][3][e] : 0.f;
+              const uint2 mk = *(const uint2*)(p.mask + oe);
+              const float v0 = bf2f((bf16_t)(mk.x & 0xffffu)) > 0.f ? acc[i][0][e] : 0.f, v1 = bf2f((bf16_t)(mk.x >> 16)) > 0.f ? acc[i][1][e] : 0.f;
+              const float v2 = bf2f((bf16_t)(mk.y & 0xffffu)) > 0.f ? acc[i][2][e] : 0.f, v3 = bf2f((bf16_t)(mk.y >> 16)) > 0.f ? acc[i][3][e] : 0.f;
               o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
               o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
             } else {
@@ -339,6 +411,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
             }
             *(uint2*)(p.out + oe) = o;
           }
+        }
       }
     }
     if (!has_next) {
