@@ -145,11 +145,12 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     p.x_sx = 16; p.x_sy = 64; p.x_img_stride = 49LL * 64;
     p.y_sx = 16 * 32; p.y_sy = 55 * 32; p.y_img_stride = 55LL * 55 * 32;
     p.koff = I(b->o_koff_c); p.M = (long long)F * 196; p.N = 704; p.nk = 1; p.ldw = 704; p.k_valid = 16;
-    for (int u = 0; u < 7; ++u) {
-      p.y_org = u * 55 * 32;
-      p.dW = Fp(b->ptoep) + (size_t)u * 16 * 704;
-      RGP_TRY((launch_wgrad<T, 1>(p, s)));
-    }
+    // the 7 tap rows u of the Toeplitz filter are 7 problems of one geometry (dY shifted by u image rows): one launch
+    p.y_org = 0;
+    p.dW = Fp(b->ptoep);
+    p.nz = 7;
+    for (int u = 0; u < 7; ++u) { p.zy[u] = (long long)u * 55 * 32 * sizeof(T); p.zw[u] = (long long)u * 16 * 704; }
+    RGP_TRY((launch_wgrad<T, 1>(p, s)));
     head_fold_toeplitz_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(Fp(b->ptoep), Fp(b->dgp));
     RGP_HIP(hipGetLastError());
   }
@@ -269,21 +270,22 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     p.X = Tp(g->E); p.x_sx = P; p.x_sy = 9 * P; p.x_img_stride = 81LL * P; p.y_img_stride = 243LL * S;
     p.koff = I(g->xconv.koff_off); p.nk = g->xconv.nk; p.k_valid = 9 * P;
     float* dWx[3] = {(float*)gr->gru_Wz, (float*)gr->gru_Wr, (float*)gr->gru_W};
-    for (int q = 0; q < 3; ++q) {
-      p.dY = Tp(b->dxpre_pad) + q * S; p.dW = dWx[q];
-      RGP_TRY((launch_wgrad<T, 1>(p, s)));
-    }
+    // the three gates are three problems of one geometry (dY columns q S, their own dW): one grouped launch
+    p.dY = Tp(b->dxpre_pad); p.dW = dWx[0]; p.nz = 3;
+    for (int q = 0; q < 3; ++q) { p.zy[q] = (long long)q * S * sizeof(T); p.zw[q] = dWx[q] - dWx[0]; }
+    RGP_TRY((launch_wgrad<T, 1>(p, s)));
     // recurrent filters: image = clip b, z = step t (h images are step-major, gradient frames clip-major)
     wgrad_grid(p, T_, 7, 7);
     p.x_sx = S; p.x_sy = 9 * S; p.x_sz = B * 81 * S; p.x_img_stride = 81LL * S;
     p.y_sz = 243 * S; p.y_img_stride = (long long)T_ * 243 * S;
     p.koff = I(g->gzr.koff_off); p.nk = g->gzr.nk; p.k_valid = 9 * S;
     float* dWh[3] = {(float*)gr->gru_Uz, (float*)gr->gru_Ur, (float*)gr->gru_U};
+    p.X = Tp(b->hp_all); p.dY = Tp(b->dxpre_pad); p.dW = dWh[0]; p.nz = 3;
     for (int q = 0; q < 3; ++q) {
-      p.X = q < 2 ? Tp(b->hp_all) : Tp(b->rhp_all);
-      p.dY = Tp(b->dxpre_pad) + q * S; p.dW = dWh[q];
-      RGP_TRY((launch_wgrad<T, 1>(p, s)));
+      p.zx[q] = q < 2 ? 0 : (const char*)Tp(b->rhp_all) - (const char*)Tp(b->hp_all);
+      p.zy[q] = (long long)q * S * sizeof(T); p.zw[q] = dWh[q] - dWh[0];
     }
+    RGP_TRY((launch_wgrad<T, 1>(p, s)));
   }
   {  // projection: one row per (frame, position), X = the 1024-channel C3D rows, dY = dE behind its zero row
     WgradParams p = wg_params();

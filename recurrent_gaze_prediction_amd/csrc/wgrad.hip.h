@@ -47,6 +47,11 @@ struct WgradParams {
   int k_valid;             // rows of dW that exist (<= nk*BKE); the rest of the last chunk is channel padding
   int steps_per_split;     // 32-row steps per blockIdx.y
   int ablate;              // dev diagnostics (RGP_WG_ABLATE): 1 = no reads/MFMA, 2 = no in-loop DMA, 4 = no barrier; results are garbage
+  // Several problems of ONE geometry in one launch (gridDim.z = nz): problem z reads its images at X + zx[z] / dY + zy[z]
+  // (bytes) and accumulates into dW + zw[z] (elements).  The out-of-range fall-back rows stay at X / dY themselves.  The
+  // head's filter gradients are a dozen launches of a few hundred 32-row steps each: grouped, one launch fills the chip.
+  int nz = 1;
+  long long zx[8] = {0}, zy[8] = {0}, zw[8] = {0};
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
   auto issue = [&](int buf) {
     char* xb = smem + buf * S::STAGE;
     char* yb = xb + S::XB;
-    const char* ximg = (const char*)p.X + img0 * p.x_img_stride * ESZ;
-    const char* yimg = (const char*)p.dY + img0 * p.y_img_stride * ESZ;
+    const char* ximg = (const char*)p.X + p.zx[blockIdx.z] + img0 * p.x_img_stride * ESZ;
+    const char* yimg = (const char*)p.dY + p.zy[blockIdx.z] + img0 * p.y_img_stride * ESZ;
     unsigned xo[2], yo[NYL];
 #pragma unroll
     for (int u = 0; u < 2; ++u) xo[u] = tx + xk[u];
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(512, WNT == 4 && sizeof(T) == 2 ? 4 : 2) void wgrad
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const long long k = (long long)kc * BKE + i * 16 + g * 4 + r;
-            if (k < p.k_valid) atomicAdd(p.dW + k * p.ldw + n, acc[i][j][r]);
+            if (k < p.k_valid) atomicAdd(p.dW + p.zw[blockIdx.z] + k * p.ldw + n, acc[i][j][r]);
           }
         }
       }

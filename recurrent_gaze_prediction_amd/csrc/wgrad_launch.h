@@ -23,7 +23,8 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
   // M = B T 49 rows) gets ONE round of blocks instead (2 per CU for the 128-wide tile, 1 for the 256-wide one): its
   // atomic traffic, not its MFMAs, is what takes the time (cfg-4 training step 2.79 -> 2.38 ms, B 64 x T 16 4.23 -> 3.81).
   const int target = dev_knob("RGP_WGK_BLOCKS", 1024);
-  const int tiles = n_kt * n_nt;
+  const int nz = std::max(1, std::min(p.nz, 8));
+  const int tiles = n_kt * n_nt * nz;
   long long splits = std::max<long long>(8, target / tiles);
   splits = std::min(splits, total_steps);
   if (total_steps / splits < 256) {
@@ -41,7 +42,7 @@ int launch_wgrad_t(const WgradParams& p, hipStream_t s) {
   q.ablate = dev_knob("RGP_WG_ABLATE", 0);
   q.steps_per_split = (int)((total_steps + splits - 1) / splits);
   splits = (total_steps + q.steps_per_split - 1) / q.steps_per_split;
-  kern<<<dim3(n_kt * n_nt, (unsigned)splits), 512, smem, s>>>(q);
+  kern<<<dim3(n_kt * n_nt, (unsigned)splits, (unsigned)nz), 512, smem, s>>>(q);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
