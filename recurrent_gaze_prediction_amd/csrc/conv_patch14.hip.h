@@ -272,6 +272,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
     {
       const Slot a0 = slot_of(bt, 0), a3 = slot_of(bt, 3);
       zpu = (a3.valid && a0.zp == a3.zp) ? a0.zp : -1;
+      if (RGP_CP_ABL(p, 16)) zpu = -1;                        // dev: no tap group skipped (timing of the layout alone)
     }
     const int mode_k0 = zpu == 0 ? (wm == 0 ? 1 : 2) : 0;     // kz = 0 on pooled plane 0: the dz = 0 slots are idle
     const int mode_k2 = zpu == 1 ? (wm == 0 ? 2 : 1) : 0;     // kz = 2 on pooled plane 1: the dz = 1 slots are idle

@@ -41,7 +41,7 @@ static int run_conv_patch14(rgp_c3d* c, int layer, int n, hipStream_t s) {
   p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[layer].argmax_off) : nullptr;
   p.mask = nullptr;
   p.n_windows = n;
-  p.ablate = 0;
+  p.ablate = dev_knob("RGP_CP_ABLATE", 0);
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
   auto kern = conv_patch14_bf16_kernel<CIN, POOL, ARGMAX>;
