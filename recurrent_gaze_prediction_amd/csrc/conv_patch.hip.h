@@ -149,6 +149,15 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   };
   int t_seq = blockIdx.x;
   if (t_seq >= nt) return;
+#ifdef RGP_DEV_KNOBS
+  // dev experiment (RGP_CP_ABLATE bits 8..15 = n): block i of an XCD starts i * n * 0.43 us late, so that the 32 CUs of an
+  // XCD read the filter out of phase (every slab is then re-touched 32 times per tile time instead of once: it stays in
+  // L2).  Measured: traffic beyond L2 falls, time RISES -- the re-streams are not what these kernels wait for.
+  if ((p.ablate >> 8) & 0xff) {
+    const int n = ((p.ablate >> 8) & 0xff) * (blockIdx.x >> 3);
+    for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
 
   // source of plane k of (tile, channel sweep cc)
   auto plane_src = [&](int tile, int cc, int k) -> const char* {
