@@ -214,12 +214,12 @@ def test_end_to_end_metrics_gate_T16(gpu, dtype):
     rows -> gaze_grcn head (bf16: patch kernels + persistent ConvGRU) -> per-frame softmax, against the fp32 CPU oracle
     of the SAME chain (torch_ref.c3d_forward -> grcn_forward): cc, sim, AUC_Judd, AUC_Borji of the 48 maps
     (evaluation_metrics.py:239-295; seeds as in test_saliency_metrics_within_1e3_of_oracle) within +-1e-3 for
-      A  the random-init head (nearly flat maps) on independent gaze data,
       B  peaked maps (output layer scaled to a logit range of ~12) on fixations that FOLLOW the oracle's maps -- the
-         regime of a trained model, AUC well above chance.
-    C  peaked maps scored on fixations that are independent of them sit at chance (AUC ~ 0.52): there a metric is a
-       rank statistic of noise and a bf16 perturbation of the logits moves AUC_Borji by a few 1e-3 (measured 5.0e-3);
-       the gate for that case is 1e-2 in bf16 and stays 1e-3 for the f32 plans."""
+         regime of a trained model, AUC well above chance: all four metrics within +-1e-3, bf16 and f32;
+      A  the random-init head (nearly flat maps) and  C  the peaked maps, both scored on gaze data that is INDEPENDENT of
+         them: cc and sim within +-1e-3; the AUCs sit at chance (0.51-0.58) there, where they are rank statistics of noise
+         and a bf16 perturbation of the logits moves AUC_Borji by a few 1e-3 (measured: 1.4e-3 in A, 5.0e-3 in C) -- gate
+         1e-2 for the two AUCs in bf16, 1e-3 for the f32 plans."""
     from recurrent_gaze_prediction_amd.engine import C3DEngine, GrcnEngine
     B, T = 3, 16
     n = B * T
@@ -252,15 +252,17 @@ def test_end_to_end_metrics_gate_T16(gpu, dtype):
         head.status()
         got = probs.cpu().numpy().reshape(n, 49, 49)
         assert np.isfinite(got).all()
-        cases = {'A': (gt, fix, 1e-3)} if label == 'A' else \
-            {'B': _fixations_following(ref, 69) + (1e-3,), 'C': (gt, fix, 1e-2 if dtype == 'bf16' else 1e-3)}
-        for name, (g_, f_, tol) in cases.items():
+        chance_auc_tol = 1e-2 if dtype == 'bf16' else 1e-3
+        cases = {'A': (gt, fix, chance_auc_tol)} if label == 'A' else \
+            {'B': _fixations_following(ref, 69) + (1e-3,), 'C': (gt, fix, chance_auc_tol)}
+        for name, (g_, f_, auc_tol) in cases.items():
             s_ref, s_got = _metric_scores(ref, g_, f_, n), _metric_scores(got, g_, f_, n)
             for metric in s_ref:
                 report[(name, metric)] = (round(s_ref[metric], 5), round(s_got[metric], 5))
+                tol = auc_tol if metric.startswith('AUC') else 1e-3
                 if not abs(s_ref[metric] - s_got[metric]) < tol:
                     bad[(name, metric)] = report[(name, metric)]
     assert not bad, (bad, report)
     assert report[('B', 'AUC_Judd')][0] > 0.8 and report[('B', 'AUC_Borji')][0] > 0.65, report      # B really is the trained-like regime
-    assert abs(report[('C', 'AUC_Borji')][0] - 0.5) < 0.1, report                                    # C really sits at chance
+    assert abs(report[('C', 'AUC_Borji')][0] - 0.5) < 0.1 and abs(report[('A', 'AUC_Borji')][0] - 0.5) < 0.1, report   # A, C sit at chance
     print('metrics gate %s: %s' % (dtype, report))
