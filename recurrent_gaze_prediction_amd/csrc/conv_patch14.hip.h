@@ -8,8 +8,8 @@
 //    shared by neighbouring pooled rows are fetched twice, 64 KB per 27 K steps against the 432 KB of filter slabs.  A
 //    block tile is 4 consecutive slots = 28 pooling windows = 224 positions x 256 channels (waves 2 (M) x 4 (N)); the 512
 //    output channels are two column tiles that follow each other in the tile order (the second finds the patch in L2).
-//    Slots are numbered (pooled plane zp, clip window, pooled row yp), so that a block tile lies in ONE pooled plane
-//    (one tile of the launch straddles the two).
+//    Slots are numbered (chunk of 4 clip windows, pooled plane zp, window, pooled row yp), so that a block tile lies in
+//    ONE pooled plane (only tiles of a short last chunk can straddle the two; they skip nothing).
 //  * fragments are dz-PURE: a 16-row m-tile is 4 pooling windows x (dy, dx) of one output plane z = 2 zp + dz.  The depth
 //    is 4 with padding 1, so output plane z = 0 multiplies its kz = 0 taps with the zero halo plane z = -1, and z = 3 its
 //    kz = 2 taps with the halo plane z = 4: in a tile of pooled plane 0 the dz = 0 fragments skip the kz = 0 tap group, in
@@ -79,7 +79,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
 
   // tiles: (block tile b = slots 4b .. 4b+3 of the 14 n_windows, column tile ct), ct innermost; dealt to the XCDs in
   // contiguous ranges
-  const int n_slots = 14 * p.n_windows;                      // pooled rows, numbered (zp, clip window, yp)
+  const int n_slots = 14 * p.n_windows;                      // pooled rows
   const int nt = ((n_slots + 3) >> 2) * C::NCT;
   auto tile_of = [&](int t) {
     const int q = nt >> 3, r = nt & 7, x = t & 7, y = t >> 3;
@@ -88,24 +88,29 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
   int t_seq = blockIdx.x;
   if (t_seq >= nt) return;
 
-  // pooled row of slot u (0 .. 3) of block tile b
+  // pooled row of slot u (0 .. 3) of block tile b.  Slots are numbered (chunk of 4 clip windows, pooled plane zp, window,
+  // pooled row yp): 28 slots = 7 block tiles per pooled plane of a chunk, so no tile of a full chunk straddles the two
+  // planes, and the two planes of a window (which share input planes 1, 2) are 7 block tiles apart: same XCD, same round
   struct Slot { int n, zp, yp; bool valid; };
   auto slot_of = [&](int b, int u) {
     Slot s;
     int g = 4 * b + u;
     s.valid = g < n_slots;
     if (!s.valid) g = n_slots - 1;
-    s.zp = g >= 7 * p.n_windows ? 1 : 0;
-    const int r = g - s.zp * 7 * p.n_windows;
-    s.n = r / 7;
-    s.yp = r - s.n * 7;
+    const int q = g / 56, r = g - 56 * q;
+    const int cw = min(4, p.n_windows - 4 * q);               // windows of this chunk (the last one may be short)
+    s.zp = r >= 7 * cw ? 1 : 0;
+    const int rr = r - s.zp * 7 * cw;
+    const int nn = rr / 7;
+    s.n = 4 * q + nn;
+    s.yp = rr - nn * 7;
     return s;
   };
-  // window w (0 .. 3) of fragment f (0 .. 6): two windows of the even slots, two of the odd slots -> (slot u, column xp)
+  // window w (0 .. 3) of fragment f (0 .. 6) = column xp = f of slot u: w = 0, 1 -> the even slots 0, 2; w = 2, 3 -> the odd
+  // slots 1, 3 (whose LDS rows start 32 bytes late: the bank argument of the header)
   auto frag_window = [](int f, int w, int& u, int& xp) {
-    const int j = 2 * f + (w & 1);
-    u = 2 * (j / 7) + (w >> 1);
-    xp = j - 7 * (j / 7);
+    u = 2 * (w & 1) + (w >> 1);
+    xp = f;
   };
   // the two input rows (of plane k, channel sweep cc) this wave fetches for a tile: slot wave >> 1, rows 2 (wave & 1), +1
   const int dpix = lane >> 2, dchk = lane & 3;
@@ -150,14 +155,17 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
   // f = i - 4 + 4 wm); row frow of a fragment: window frow >> 2, (dy, dx) = ((frow >> 1) & 1, frow & 1); K chunk fk
   auto frag_of = [&](int i) { return i < 4 ? 3 * wm + i : i - 4 + 4 * wm; };
   const int r_dy = (frow >> 1) & 1, r_dx = frow & 1;
-  // ra[i]: LDS address of this lane's row of slot i in the plane its dz reads for the CURRENT tap group (kz + dz);
-  // advanced in place by one plane per tap group and taken back by two at the end of a sweep
-  unsigned ra[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
+  // LDS address of this lane's row (window frow >> 2, (dy, dx)) of fragment column 0 in the plane its dz reads for the
+  // CURRENT tap group (kz + dz): ra_lo for accumulator slots 0 .. 3 (dz = wm, columns 3 wm + i), ra_hi for slots 4 .. 6
+  // (dz = 1 - wm, columns 4 wm + i - 4); the column is an immediate of 128 bytes per fragment.  Advanced in place by one
+  // plane per tap group and taken back by two at the end of a sweep.
+  unsigned ra_lo, ra_hi;
+  {
     int u, xp;
-    frag_window(frag_of(i), frow >> 2, u, xp);
-    ra[i] = lds0 + (u * 4 + r_dy) * C::LROW + 32 * (u & 1) + (2 * xp + r_dx) * 64 + fk * 16 + plane_base(i < 4 ? wm : 1 - wm);
+    frag_window(0, frow >> 2, u, xp);
+    const unsigned base = lds0 + (u * 4 + r_dy) * C::LROW + 32 * (u & 1) + r_dx * 64 + fk * 16;
+    ra_lo = base + (3 * wm) * 128 + plane_base(wm);
+    ra_hi = base + (4 * wm) * 128 + plane_base(1 - wm);
   }
   const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
   const int cg = tid % C::CGN;
@@ -202,8 +210,17 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         auto reads = [&](auto T9) {
           constexpr int t = decltype(T9)::value;
           constexpr int imm = (t / 3) * C::LROW + (t % 3) * 64;
-#pragma unroll
-          for (int i = I0; i < I1; ++i) af[i] = cp_lds_read128<imm>(ra[i]);
+          if constexpr (I0 < 4) {
+            af[0] = cp_lds_read128<imm>(ra_lo);
+            af[1] = cp_lds_read128<imm + 128>(ra_lo);
+            af[2] = cp_lds_read128<imm + 256>(ra_lo);
+            af[3] = cp_lds_read128<imm + 384>(ra_lo);
+          }
+          if constexpr (I1 > 4) {
+            af[4] = cp_lds_read128<imm>(ra_hi);
+            af[5] = cp_lds_read128<imm + 128>(ra_hi);
+            af[6] = cp_lds_read128<imm + 256>(ra_hi);
+          }
         };
         switch (t9) {
           case 0: reads(std::integral_constant<int, 0>{}); break;
@@ -258,8 +275,8 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
       }
       // next tap group: one plane further (after kz = 2: back to the planes of kz = 0)
-#pragma unroll
-      for (int i = 0; i < 7; ++i) ra[i] += kz == 2 ? (unsigned)(-2 * C::PLANE_STRIDE) : (unsigned)C::PLANE_STRIDE;
+      ra_lo += kz == 2 ? (unsigned)(-2 * C::PLANE_STRIDE) : (unsigned)C::PLANE_STRIDE;
+      ra_hi += kz == 2 ? (unsigned)(-2 * C::PLANE_STRIDE) : (unsigned)C::PLANE_STRIDE;
     };
     using I0_ = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

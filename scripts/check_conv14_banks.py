@@ -1,8 +1,8 @@
 """Dev check: LDS layout of conv_patch14.hip.h (dz-pure fragments) is bank-conflict free for every ds_read_b128.
 
-Fragment f (0..6) of a block tile: rows 0-3 / 4-7 = windows E[2f], E[2f+1] of the even slots (u = 0, 2), rows 8-11 /
-12-15 = windows O[2f], O[2f+1] of the odd slots (u = 1, 3); row e of a window = (dy, dx) = (e >> 1, e & 1); all 16 rows
-read the same plane.  LDS byte address = (4 u + dy + ky) 1152 + 32 (u & 1) + (2 xp + dx + kx) 64 + 16 fk."""
+Fragment f (0..6) of a block tile = column xp = f of its four slots: rows 0-3 / 4-7 = the windows of the even slots u = 0, 2,
+rows 8-11 / 12-15 = those of the odd slots u = 1, 3; row e of a window = (dy, dx) = (e >> 1, e & 1); all 16 rows read the
+same plane.  LDS byte address = (4 u + dy + ky) 1152 + 32 (u & 1) + (2 xp + dx + kx) 64 + 16 fk."""
 GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
           list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
           list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
@@ -11,8 +11,7 @@ LROW = 1152
 
 
 def window(f, w):
-    j = 2 * f + (w & 1)
-    return 2 * (j // 7) + (w >> 1), j % 7        # (slot u, xp): w = 0, 1 even slots, w = 2, 3 odd slots
+    return 2 * (w & 1) + (w >> 1), f             # (slot u, xp): w = 0, 1 -> even slots 0, 2; w = 2, 3 -> odd slots 1, 3
 
 
 def main():
