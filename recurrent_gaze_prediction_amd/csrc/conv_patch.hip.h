@@ -106,6 +106,13 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static_assert((STG_LD * 2) % 16 == 0 && STG_LD % 8 == 0, "staging rows keep 16- / 8-byte alignment");
 };
 
+// max of MFMA results without the compiler's canonicalising `v_max_f32 x, x, x` in front of every operand (IEEE mode: the
+// hardware instruction quiets a signalling NaN itself and, like fmaxf, returns the other operand for a NaN): 77 of the
+// 224 v_max of conv2a's pooled epilogue were such moves once the kernels left the -fno-honor-nans translation unit
+static __device__ __forceinline__ float cp_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+static __device__ __forceinline__ float cp_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+static __device__ __forceinline__ float cp_relu(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+
 template <int OFF>
 static __device__ __forceinline__ f32x4 cp_lds_read128(unsigned addr) {
   f32x4 v;
@@ -384,9 +391,9 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
             pv[j] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
             pc |= (unsigned)(ob > best ? oi + 4 : idx) << (8 * j);
           } else {
-            const float x = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+            const float x = cp_max(cp_max3(c[0], c[1], c[2]), c[3]);
             const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-            pv[j] = f2bf(fmaxf(fmaxf(x, y) + b4[j], 0.f));
+            pv[j] = f2bf(cp_relu(cp_max(x, y) + b4[j]));
           }
         }
         if ((fk & 1) == 0) {

@@ -4,8 +4,11 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if sys.argv[1] == '--child':
+    import ctypes
     from recurrent_gaze_prediction_amd import _lib
     _lib.LIB_PATH = sys.argv[2]
+    _probe = ctypes.CDLL(sys.argv[2])                      # an older build lacks the newer entry points: bind what it has
+    _lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_probe, k)}
     import torch
     from recurrent_gaze_prediction_amd import synthetic as syn
     from recurrent_gaze_prediction_amd.engine import C3DEngine
