@@ -38,8 +38,8 @@
 
 namespace rgp {
 
-template <int CIN, bool POOL> struct Patch14Cfg {
-  static constexpr int NOUT = 512, TN = 256;              // output channels, channels per tile (waves 2 x 4)
+template <int CIN, bool POOL, int NOUT_ = 512> struct Patch14Cfg {
+  static constexpr int NOUT = NOUT_, TN = 256;            // output channels (512; 256: conv4a's input gradient), channels per tile (waves 2 x 4)
   static constexpr int NCT = NOUT / TN;                   // column tiles
   static constexpr int NCC = CIN / 32;                    // channel sweeps: 8 / 16
   static constexpr int LROW = 1152;                       // LDS row pitch (16 pixels x 64 B + 128)
@@ -62,11 +62,14 @@ template <int CIN, bool POOL> struct Patch14Cfg {
   static_assert(LROW % 256 == 128, "row pitch = 128 (mod 256)");
 };
 
-template <int CIN, bool POOL, bool ARGMAX = false, bool DGRAD = false>
+// DENSE (DGRAD only): the output is the dense, un-masked [n][4*14*14][NOUT] image the un-pool kernel consumes (conv4a's
+// input gradient, NOUT = 256: the gradient w.r.t. pool3's output).
+template <int CIN, bool POOL, bool ARGMAX = false, bool DGRAD = false, int NOUT = 512, bool DENSE = false>
 static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const ConvPatchParams p) {
   static_assert(POOL || !ARGMAX, "arg-max codes belong to the pooled layer");
   static_assert(!POOL || !DGRAD, "the input gradient is an un-pooled convolution");
-  using C = Patch14Cfg<CIN, POOL>;
+  static_assert(!DENSE || DGRAD, "dense output: input gradients only");
+  using C = Patch14Cfg<CIN, POOL, NOUT>;
   extern __shared__ __attribute__((aligned(16))) char cq_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cq_smem;
   const int tid = threadIdx.x;
@@ -411,13 +414,20 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         const Slot sl = slot_of(bt, u);
         const int dz = i < 4 ? wm : 1 - wm;
         if (sl.valid) {
-          const long long ow = (long long)sl.n * C::OUT_IMG + (2 * sl.zp + dz + 1) * C::OUT_PLANE + (2 * sl.yp + 1) * C::OUT_ROW + (2 * xp + 1) * C::NOUT +
+          // position (z, y, x) = (2 zp + dz, 2 yp + dy, 2 xp + dx): halo-padded image, or (DENSE) natural order without halo
+          constexpr int ROWS = DENSE ? 14 * C::NOUT : C::OUT_ROW, PLANES = DENSE ? 14 * ROWS : C::OUT_PLANE;
+          constexpr long long IMG = DENSE ? 4LL * PLANES : (long long)C::OUT_IMG;
+          constexpr int H1 = DENSE ? 0 : 1;
+          const long long ow = (long long)sl.n * IMG + (2 * sl.zp + dz + H1) * PLANES + (2 * sl.yp + H1) * ROWS + (2 * xp + H1) * C::NOUT +
                                ct * C::TN + wn * 64 + frow * 4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const long long oe = ow + (e >> 1) * C::OUT_ROW + (e & 1) * C::NOUT;
+            const long long oe = ow + (e >> 1) * ROWS + (e & 1) * C::NOUT;
             uint2 o;
-            if constexpr (DGRAD) {
+            if constexpr (DGRAD && DENSE) {
+              o.x = (unsigned)f2bf(acc[i][0][e]) | ((unsigned)f2bf(acc[i][1][e]) << 16);
+              o.y = (unsigned)f2bf(acc[i][2][e]) | ((unsigned)f2bf(acc[i][3][e]) << 16);
+            } else if constexpr (DGRAD) {
               const uint2 mk = *(const uint2*)(p.mask + oe);
               const float v0 = bf2f((bf16_t)(mk.x & 0xffffu)) > 0.f ? acc[i][0][e] : 0.f, v1 = bf2f((bf16_t)(mk.x >> 16)) > 0.f ? acc[i][1][e] : 0.f;
               const float v2 = bf2f((bf16_t)(mk.y & 0xffffu)) > 0.f ? acc[i][2][e] : 0.f, v3 = bf2f((bf16_t)(mk.y >> 16)) > 0.f ? acc[i][3][e] : 0.f;

@@ -222,7 +222,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     IgemmParams p = make_params(b.dg, ws + b.dypre_off, ws, n);
     p.tile128 = c->tile128();
     if (pooled(i - 1)) {
-      if (sizeof(T) == 2 && c->use_patch() && (i == 1 || i == 2 || i == 6) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
+      if (sizeof(T) == 2 && c->use_patch() && (i == 1 || i == 2 || i == 4 || i == 6) && b.dg.chunk_major == 64 && dev_knob("RGP_DGPATCH", 1)) {
         RGP_TRY(run_conv_patch_dgrad_bf16(c, i, n, s));      // conv_patch.hip.h, dense output
       } else {
         EpiParams e = make_epi(b.dg, ws + c->dyp_off, ws);

@@ -62,7 +62,7 @@ struct rgp_c3d {
 // rgp_conv1a.hip: the dedicated bf16 conv1a + pool1 kernel (video != nullptr: reads the fp32 windows directly)
 int run_conv1a_bf16(rgp_c3d* c, int n, hipStream_t s, const float* video = nullptr);
 int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s);   // layers 1 ... 7
-int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s);   // layers 1, 2, 6 (dense), 3, 5, 7 (masked); training plans
+int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s);   // layers 1, 2, 4, 6 (dense), 3, 5, 7 (masked); training plans
 // rgp_c3d_bwd.hip
 int c3d_bwd_plan(rgp_c3d* c, rgp::Arena& a);                                      // tables + workspace layout
 int c3d_bwd_upload(rgp_c3d* c, hipStream_t s);

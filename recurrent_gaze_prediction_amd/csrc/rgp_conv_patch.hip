@@ -123,6 +123,13 @@ int run_conv_patch_dgrad_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
     constexpr int smem = Patch14Cfg<512, false>::SMEM;
     RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
     kern<<<n_cu, 512, smem, s>>>(p);
+  } else if (layer == 4) {                                   // conv4a: dense [n][784][256] for the un-pool kernel (pool3)
+    p.out = (bf16_t*)(c->ws + c->dyp_off);
+    p.mask = nullptr;
+    auto kern = conv_patch14_bf16_kernel<512, false, false, true, 256, true>;
+    constexpr int smem = Patch14Cfg<512, false, 256>::SMEM;
+    RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+    kern<<<n_cu, 512, smem, s>>>(p);
   } else if (layer == 7) {                                   // conv5b: masked by conv5a's activation, written as dY of conv5a
     auto kern = conv_patch7_bf16_kernel<0, true>;
     RGP_TRY(ensure_dyn_smem((const void*)kern, Patch7Cfg::SMEM));
