@@ -347,19 +347,16 @@ template <int P> __device__ __forceinline__ void pool_window_argmax(const float*
   *(uint2*)amax = make_uint2(lo, hi);
 }
 
-template <int BM, int BN, int NS = 2> struct IgemmSmem {
+template <int BM, int BN> struct IgemmSmem {
   static constexpr int TILE_BYTES = (BM + BN) * 128;
-  static constexpr int ROWINFO_OFF = NS * TILE_BYTES;
+  static constexpr int ROWINFO_OFF = 2 * TILE_BYTES;
   static constexpr int BYTES = ROWINFO_OFF + BM * 24;   // int64 rowin + int img + int ml + int64 rowout per row
 };
 
 // G = K-subchunks per 128-byte chunk that carry their own tap offset (1 for
 // Cin*sizeof(T) >= 128 B; 2/4 when a 128-B chunk spans several taps).
 // P = rows per pooling window (1, 4 or 8), rows of a window are consecutive in m.
-// NS = LDS stages of the K loop.  2: double buffer, every K-tile waits for its successor's DMA (fine while a tile's MFMAs
-// outlast the DMA latency).  NS > 2: a ring with NS - 2 tiles in flight behind a counted vmcnt, for the skinny GEMMs
-// (64 x 16 tiles: 8 MFMAs per wave and K-tile, far less than one L2 / Infinity-Cache round trip).
-template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi, int NS = 2>
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p, const EpiParams e) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -371,7 +368,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
   static_assert(WTM % P == 0, "pool window inside a slab");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  long long* s_rowin = (long long*)(smem + IgemmSmem<BM, BN, NS>::ROWINFO_OFF);
+  long long* s_rowin = (long long*)(smem + IgemmSmem<BM, BN>::ROWINFO_OFF);
   int* s_rowimg = (int*)(s_rowin + BM);
   int* s_rowml = s_rowimg + BM;
   long long* s_rowout = (long long*)(s_rowml + BM);   // output offset of the row's pooling window, resolved here
@@ -466,20 +463,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fk = lane >> 4;
-  f32x4 acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};      // skinny tiles (one MFMA tile per wave): second accumulation chain
   auto compute = [&](int buf) {
     const char* abuf = smem + buf * TILE_BYTES + (wm * WTM + frow) * 128;
     const char* bbuf = smem + buf * TILE_BYTES + BM * 128 + (wn * WTN + frow) * 128;
-    if constexpr (MI == 1 && NI == 1) {
-      // a single 16 x 16 tile per wave: the K-tile's fragments are read up front and its two halves run on two
-      // accumulators -- one dependent MFMA chain of 8 with an LDS round trip in the middle otherwise
-      const int pc0 = ((fk) ^ (frow & 7)) * 16, pc1 = ((4 + fk) ^ (frow & 7)) * 16;
-      const f32x4 a0 = *(const f32x4*)(abuf + pc0), b0 = *(const f32x4*)(bbuf + pc0);
-      const f32x4 a1 = *(const f32x4*)(abuf + pc1), b1 = *(const f32x4*)(bbuf + pc1);
-      Mma<T>::step(acc[0][0], a0, b0);
-      Mma<T>::step(acc_b, a1, b1);
-      return;
-    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int pc = ((s * 4 + fk) ^ (frow & 7)) * 16;
@@ -495,7 +481,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     }
   };
 
-  if constexpr (NS == 2) {
   stage(0, kt_begin, ko_first);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -513,45 +498,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     __syncthreads();
     cur ^= 1;
   }
-  } else {
-    // ring of NS slots: tiles kt+1 .. kt+NS-2 are in flight while tile kt is multiplied.  The slot refilled in iteration
-    // kt (with tile kt+NS-1) is the one multiplied in iteration kt-1: its DMA is issued behind the barrier that every wave
-    // reaches after that compute.
-    static_assert(G == 1 && NS >= 3 && NS <= 8, "ring variant: plain K schedule");
-    constexpr int IPW_FULL = A_PER_WAVE + B_PER_WAVE;          // DMA instructions per stage of a wave that also stages B
-    // the K-offset table through the SCALAR cache (constant address space): a vector load here would sit in the vmcnt
-    // queue the counted waits below are written for, and the compiler would drain the ring to consume it
-    auto load_koff_s = [&](int kt) -> int {
-      kt = kt < p.nk ? kt : p.nk - 1;
-      return ((const __attribute__((address_space(4))) int*)p.koff)[kt];
-    };
-#pragma unroll
-    for (int u = 0; u < NS - 1; ++u)
-      if (kt_begin + u < kt_end) stage(u, kt_begin + u, load_koff_s(kt_begin + u));
-    int ko_ring = load_koff_s(kt_begin + NS - 1);
-    int slot = 0, fill = NS - 1;
-#pragma clang loop unroll(disable)
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      // tile kt landed: younger are the NS - 2 tiles issued after it (the last NS - 2 iterations simply drain)
-      if (kt + NS - 2 < kt_end) {
-        if (b_active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW_FULL * (NS - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PER_WAVE * (NS - 2)) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      if (kt + NS - 1 < kt_end) {
-        stage(fill, kt + NS - 1, ko_ring);
-        ko_ring = load_koff_s(kt + NS);
-      }
-      compute(slot);
-      slot = slot + 1 == NS ? 0 : slot + 1;
-      fill = fill + 1 == NS ? 0 : fill + 1;
-    }
-    __syncthreads();                                            // staging below reuses the tile buffers
-  }
 
-  if constexpr (MI == 1 && NI == 1) acc[0][0] += acc_b;
   // ---- epilogue: one wave-row slab (WTM rows x BN cols, fp32) at a time ----
   constexpr int LDS_LD = BN + 4;
   float* stg = (float*)smem;
@@ -597,6 +544,145 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
       }
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny GEMM: ONE row tile (M <= 64) and a wide output -- the fc-GRU recurrence (M = B = 64 rows, N = 3248 / 1624, K = 1624,
+// /root/reference/models/gaze_rnn.py:315-349).  A block owns 16 output columns of all 64 rows, so the columns spread over
+// N / 16 = 203 / 102 CUs; the K reduction is split over the 16 waves of the block -- wave w = (row tile w & 3, K slice
+// w >> 2) -- so that a barrier interval covers FOUR K-tiles (13 intervals for K = 1624 instead of 51) and four waves per
+// SIMD hide each other's LDS latency.  Three LDS stages of 4 x (64 + 16) x 128 B, two in flight behind a counted vmcnt; the
+// K-offset table comes through the scalar cache.  The four slices are summed through LDS before the epilogue functor runs
+// (same functors as igemm_kernel).  G = 1, P = 1.
+struct SkinnySmem {
+  static constexpr int KT = 4;                              // K-tiles per stage
+  static constexpr int TILE = (64 + 16) * 128;              // one K-tile: 64 A rows + 16 B rows of 128 B
+  static constexpr int STAGE = KT * TILE;                   // 40 960
+  static constexpr int NS = 3;
+  static constexpr int RED_OFF = NS * STAGE;                // [4 slices][64 rows][20] fp32
+  static constexpr int ROWINFO_OFF = RED_OFF + 4 * 64 * 20 * 4;
+  static constexpr int BYTES = ROWINFO_OFF + 64 * 24;       // 144 896
+};
+
+template <typename T, class Epi>
+__global__ __launch_bounds__(1024) void igemm_skinny_kernel(const IgemmParams p, const EpiParams e) {
+  using S = SkinnySmem;
+  constexpr int ESZ = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  long long* s_rowin = (long long*)(smem + S::ROWINFO_OFF);
+  int* s_rowimg = (int*)(s_rowin + 64);
+  int* s_rowml = s_rowimg + 64;
+  long long* s_rowout = (long long*)(s_rowml + 64);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wmt = wave & 3, wq = wave >> 2;                 // row tile, K slice
+  const int n0 = blockIdx.x * 16;
+  auto load_koff = [&](int kt) -> int {
+    kt = kt < p.nk ? kt : p.nk - 1;
+    return ((const __attribute__((address_space(4))) int*)p.koff)[kt];
+  };
+  for (int r = tid; r < 64; r += 1024) {
+    int m = r;
+    const bool valid = m < p.M;
+    if (!valid) m = p.M - 1;
+    const int img = m / p.Mw, ml = m - img * p.Mw;
+    s_rowin[r] = (long long)img * p.in_img_stride + p.in_tab[ml];
+    s_rowimg[r] = valid ? img : -1;
+    s_rowml[r] = ml;
+    s_rowout[r] = valid ? epi_out_base(e, img, ml) : 0;
+  }
+  __syncthreads();
+  // DMA sources: a wave instruction fills 8 rows x 128 B (lane -> row lane >> 3, physical chunk lane & 7 = logical chunk
+  // (lane & 7) ^ (lane >> 3)); per stage 4 K-tiles x (8 A groups + 2 B groups): wave w stages A groups 2w, 2w+1 of the 32
+  // (K-tile = group >> 3), waves 0..7 also B group w of the 8
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+  const char* a_src[2];
+  int a_kt[2], a_dst[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int g = 2 * wave + j;
+    a_kt[j] = g >> 3;
+    a_src[j] = (const char*)p.A + s_rowin[(g & 7) * 8 + lrow] * ESZ + lchunk * 16;
+    a_dst[j] = a_kt[j] * S::TILE + (g & 7) * 1024;
+  }
+  const bool b_active = wave < 8;
+  const int b_kt = wave >> 1;
+  const char* b_src = (const char*)p.W + ((long long)(n0 + (wave & 1) * 8 + lrow) * p.K) * ESZ + lchunk * 16;
+  const int b_dst = b_kt * S::TILE + 64 * 128 + (wave & 1) * 1024;
+  const int n_it = (p.nk + S::KT - 1) / S::KT;              // barrier intervals; K-tiles beyond nk are clamped duplicates, never multiplied
+  auto stage = [&](int slot, int it, int ko0, int ko1) {
+    char* base = smem + slot * S::STAGE;
+    {
+      const int kt = it * S::KT + a_kt[0];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[0] + (long long)ko0 * ESZ),
+                                       (__attribute__((address_space(3))) void*)(base + a_dst[0]), 16, 0, 0);
+      (void)kt;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[1] + (long long)ko1 * ESZ),
+                                     (__attribute__((address_space(3))) void*)(base + a_dst[1]), 16, 0, 0);
+    if (b_active) {
+      int kt = it * S::KT + b_kt;
+      if (kt >= p.nk) kt = p.nk - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (long long)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(base + b_dst), 16, 0, 0);
+    }
+  };
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int slot, int it) {
+    if (it * S::KT + wq >= p.nk) return;                    // (wave-uniform) K-tile past the end
+    const char* abuf = smem + slot * S::STAGE + wq * S::TILE + (wmt * 16 + frow) * 128;
+    const char* bbuf = smem + slot * S::STAGE + wq * S::TILE + 64 * 128 + frow * 128;
+    const int pc0 = ((fk) ^ (frow & 7)) * 16, pc1 = ((4 + fk) ^ (frow & 7)) * 16;
+    const f32x4 a0 = *(const f32x4*)(abuf + pc0), b0 = *(const f32x4*)(bbuf + pc0);
+    const f32x4 a1 = *(const f32x4*)(abuf + pc1), b1 = *(const f32x4*)(bbuf + pc1);
+    Mma<T>::step(acc0, a0, b0);
+    Mma<T>::step(acc1, a1, b1);
+  };
+  // K offsets of this wave's two A groups for interval `it`
+  auto ko_of = [&](int it, int j) { return load_koff(it * S::KT + a_kt[j]); };
+  // prologue: intervals 0 and 1
+  stage(0, 0, ko_of(0, 0), ko_of(0, 1));
+  if (n_it > 1) stage(1, 1, ko_of(1, 0), ko_of(1, 1));
+  int k0 = ko_of(2, 0), k1 = ko_of(2, 1);
+  int slot = 0, fill = 2;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < n_it; ++it) {
+    // interval `it` landed: younger is (at most) interval it + 1
+    if (it + 1 < n_it) {
+      if (b_active) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (it + 2 < n_it) {
+      stage(fill, it + 2, k0, k1);
+      k0 = ko_of(it + 3, 0); k1 = ko_of(it + 3, 1);
+    }
+    compute(slot, it);
+    slot = slot + 1 == S::NS ? 0 : slot + 1;
+    fill = fill + 1 == S::NS ? 0 : fill + 1;
+  }
+  // ---- reduce the four K slices, then the epilogue functor on (row, 8 columns) items ----
+  acc0 += acc1;
+  float* red = (float*)(smem + S::RED_OFF);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wq * 64 + wmt * 16 + fk * 4 + r) * 20 + frow] = acc0[r];
+  __syncthreads();
+  if (tid < 128) {
+    const int row = tid >> 1, cgp = tid & 1;
+    const int img = s_rowimg[row];
+    if (img >= 0) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int o = row * 20 + cgp * 8 + i;
+        v[i] = red[o] + red[64 * 20 + o] + red[2 * 64 * 20 + o] + red[3 * 64 * 20 + o];
+      }
+      Epi::apply_at(e, p.N, img, s_rowml[row], s_rowout[row], n0 + cgp * 8, v);
+    }
   }
 }
 

@@ -223,10 +223,10 @@ struct PackBatch {
 };
 
 // ---- launch dispatch -------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi, int NS = 2>
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
 int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi, NS>;
-  constexpr int smem = IgemmSmem<BM, BN, NS>::BYTES;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, G, P, Epi>;
+  constexpr int smem = IgemmSmem<BM, BN>::BYTES;
   RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
   const int n_mt = (p.M + BM - 1) / BM, n_nt = (p.N + BN - 1) / BN;
   kern<<<dim3(n_mt * n_nt, ksplit), dim3(WM * WN * 64), smem, s>>>(p, e);
@@ -297,7 +297,7 @@ IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
   if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return TILE_LOOP_256x128;
   // one row tile and a wide output (the fc-GRU's recurrent GEMMs: M = B <= 64 rows, N = 1624 / 3248, K = 1624): even
   // 64x64 tiles give only 26 / 51 blocks, each bound by ONE CU's MFMA rate (40 us per launch, 32 launches per forward);
-  // 64x16 tiles (4 waves of 16x16) spread the same FLOPs over 102 / 203 CUs
+  // igemm_skinny_kernel spreads the same FLOPs over 102 / 203 CUs (64 x 16 columns per block, K split over its 16 waves)
   if constexpr (G == 1 && P == 1) {
     if (ksplit == 1 && p.M <= 64 && p.N >= 512 && (p.N + 63) / 64 < 128) return TILE_64x16;
   }
@@ -318,7 +318,7 @@ inline const char* igemm_tile_name(IgemmTile t) {
     case TILE_WIDE_512x128: return "igemm_wide_kernel<512x128";
     case TILE_STAGGER_256x128: return "igemm_stagger_kernel<256x128";
     case TILE_LOOP_256x128: return "igemm_kernel<256x128";
-    case TILE_64x16: return "igemm_kernel<64x16";
+    case TILE_64x16: return "igemm_skinny_kernel<64x16";
     case TILE_64x64: return "igemm_kernel<64x64";
     case TILE_128x128: return "igemm_kernel<128x128";
     case TILE_128x64: return "igemm_kernel<128x64";
@@ -364,7 +364,13 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
     return launch_stagger<T, P, Epi>(p, e, s);
   }
   if constexpr (G == 1 && P == 1) {
-    if (tile == TILE_64x16) return launch_cfg<T, 64, 16, 4, 1, G, P, Epi, 8>(p, e, s, ksplit);
+    if (tile == TILE_64x16) {
+      auto kern = igemm_skinny_kernel<T, Epi>;
+      RGP_TRY(ensure_dyn_smem((const void*)kern, SkinnySmem::BYTES));
+      kern<<<dim3((p.N + 15) / 16), dim3(1024), SkinnySmem::BYTES, s>>>(p, e);
+      RGP_HIP(hipGetLastError());
+      return RGP_OK;
+    }
   }
   switch (tile) {
 #ifdef RGP_DEV_KNOBS
@@ -373,8 +379,8 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
     case TILE_64x64: return launch_cfg<T, 64, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
     case TILE_128x128: return launch_cfg<T, 128, 128, 2, 2, G, P, Epi>(p, e, s, ksplit);
     case TILE_128x64: return launch_cfg<T, 128, 64, 2, 2, G, P, Epi>(p, e, s, ksplit);
-    // (the ring variant on this tile -- NS = 5, 100 KB of LDS, one block per CU instead of four -- measured 0.54 -> 0.71 ms on
-    // the head's deconvolution phases: co-resident blocks hide the K-tile latency better than a deeper ring)
+    // (a 5-stage LDS-DMA ring on this tile -- 100 KB of LDS, one block per CU instead of four -- measured 0.54 -> 0.71 ms on
+    // the head's deconvolution phases: co-resident blocks hide the K-tile latency better than a deeper ring; not kept)
     default: return launch_cfg<T, 128, 32, 4, 1, G, P, Epi>(p, e, s, ksplit);
   }
 }
