@@ -37,6 +37,23 @@
 //    them -- conservative, never early.)
 //  * schedule: the two-group staggered loop of igemm_wide.hip.h (waves 0-3 / 4-7, partners on a SIMD, half a step
 //    apart: LOAD = fragment reads + DMA issue + counted wait, COMPUTE = 28 MFMAs), waves 4 (M) x 2 (N), 112 x 64 each.
+//
+// Round 3 -- dz-pure fragments and skipped halo-plane tap groups (the scheme of conv_patch14.hip.h, read its header):
+//  * a 16-row fragment is 4 pooling windows x (dy, dx) of ONE output plane z = 2 zp + dz: the column pair (2 f, 2 f + 1) of
+//    the tile's two pooled rows, rows 0-3 = (row 0, col 2f), 4-7 = (row 1, col 2f), 8-11 = (row 1, col 2f+1), 12-15 =
+//    (row 0, col 2f+1).  A pair of M waves (m = wm & 1) shares 7 column pairs: accumulator slots 0 .. 3 of wave m hold plane
+//    dz = m of pairs 3 m + i, slots 4 .. 6 plane 1 - m of pairs 4 m + i - 4.  (conv2a has two such wave pairs, one per
+//    half of the 28 columns.)
+//  * the plane slabs are fetched row by row (4 / 2 LDS-DMA instructions of 16 pixels per row) into rows of pitch 4128 /
+//    2080 bytes = 32 (mod 256): with the fragment order above the 16 lanes of every ds_read_b128 group hit 16 different
+//    16-byte slots for every tap (scripts/check_conv_patch_banks.py); no parity shift of the plane buffers any more.  The
+//    fragment address is one register per dz set + immediates (256 bytes per column pair, ky pitch + 64 kx per tap).
+//  * output plane z = 0 multiplies its kz = 0 taps with the zero halo plane z = -1, and z = DEPTH - 1 its kz = 2 taps with
+//    the halo plane z = DEPTH: in the tiles of the first / last pooled plane the dz = 0 / dz = 1 fragments skip that tap
+//    group (12 or 16 MFMAs per wave and step instead of 28).  2 of 8 (conv2a) / 2 of 4 (conv3a, conv3b) pooled planes.
+//  * pooling: max over (dy, dx) in the lane's registers, over dz between two accumulator slots of the wave; column pair 3
+//    has its two planes in different waves, which exchange fp32 maxima through the filter-ring slot that is idle during
+//    the epilogue (conv_patch14.hip.h).
 #pragma once
 #include <type_traits>
 
@@ -75,10 +92,13 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static constexpr int NCC = CIN / 32;                    // channel sweeps: 2 / 8
   static constexpr int WIN = 2 * XPN;                     // pooling windows per tile: 56 / 28
   static constexpr int WMW = WIN / 14, WNW = 8 / WMW;     // waves along M (14 windows = 7 m-tiles each) and N
-  static constexpr int PPW = (6 * WP + 127) / 128;        // plane-slab DMA instructions per wave: 3 / 2
-  static constexpr int PLANE_PIX = PPW * 128;             // pixels fetched per slab: 384 / 256 (348 / 180 used)
-  static constexpr int PLANE_BYTES = PLANE_PIX * 64, PLANE_STRIDE = PLANE_BYTES + 256;
-  static constexpr int BRING_OFF = (3 * PLANE_STRIDE + 32 + PLANE_BYTES + 1023) / 1024 * 1024;
+  static constexpr int RPI = (WP + 15) / 16;              // LDS-DMA instructions per slab row (16 pixels x 64 B each): 4 / 2
+  static constexpr int LP = RPI * 1024 + 32;              // LDS row pitch: 4128 / 2080 bytes = 32 (mod 256)
+  static constexpr int PPW = (6 * RPI + 7) / 8;           // plane-slab DMA instructions per wave: 3 / 2
+  static constexpr int NDUMP = 8 * PPW - 6 * RPI;         // instructions beyond the 6 rows (0 / 4): they land in a dump area
+  static constexpr int PLANE_BYTES = 6 * LP + NDUMP * 1024;
+  static constexpr int PLANE_STRIDE = (PLANE_BYTES + 255) / 256 * 256;     // 24 832 / 16 640
+  static constexpr int BRING_OFF = (4 * PLANE_STRIDE + 1023) / 1024 * 1024;
   static constexpr int NI = NOUT / (16 * WNW);            // 16-column MFMA tiles per wave: 4 (2 for the 64 / 128-channel
                                                           // input gradients of conv2a / conv3a: wave tile 112 x 32)
   static constexpr int BPW = (NOUT + 127) / 128;          // filter-slab DMA instructions per wave and step: 1 / 2
@@ -89,7 +109,8 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   // its own (the filter ring keeps running across tiles)
   static constexpr int STG_LD = NOUT + 8;
   static constexpr int STGA_OFF = STG_OFF + WIN * STG_LD * 2;
-  static constexpr int SMEM = POOL ? STGA_OFF + WIN * STG_LD : STG_OFF;     // 154 944 / 154 272 (pooled layers)
+  static constexpr int BIAS_OFF = POOL ? STGA_OFF + WIN * STG_LD : STG_OFF;      // the layer's biases (fp32), read by the epilogues
+  static constexpr int SMEM = BIAS_OFF + NOUT * 4;
   static constexpr int NSTEP = NCC * 27;
   static constexpr int YT = HW / 4;                       // tiles per pooled plane
   static constexpr int TILES_PER_WINDOW = (DEPTH / 2) * YT;
@@ -100,7 +121,7 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchCf
   static constexpr int CGN = NOUT / 8;                    // epilogue: 8-channel groups
   static_assert(WNW * 16 * NI == NOUT && (NI == 4 || (NI == 2 && !POOL)) && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0,
                 "tile shape");
-  static_assert((WP * 64) % 256 == 128, "row pitch = 128 (mod 256): the bank argument of the header");
+  static_assert(LP % 256 == 32, "row pitch = 32 (mod 256): the bank argument of the header");
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(!POOL || WIN * CGN == 2 * 448, "pooled epilogue: two items per thread (448 of the 512 threads)");
   static_assert((STG_LD * 2) % 16 == 0 && STG_LD % 8 == 0, "staging rows keep 16- / 8-byte alignment");
@@ -145,7 +166,8 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   const int wm = wave / C::WNW, wn = wave % C::WNW;
   const bool group_b = wave >= 4;
   const int frow = lane & 15, fk = lane >> 4;
-  auto plane_base = [](int k) { return (unsigned)(k * C::PLANE_STRIDE + 32 * (k & 1)); };
+  const int wmm = wm & 1, wmh = wm >> 1;                     // member of its M-wave pair, column half (conv2a: 2 pairs)
+  auto plane_base = [](int k) { return (unsigned)(k * C::PLANE_STRIDE); };
 
   // persistent tile walk: XCD x (workgroup id & 7) owns a contiguous range of tiles (neighbouring tiles share halo rows
   // and planes: one L2 serves them)
@@ -173,23 +195,22 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     if (RGP_CP_ABL(p, 1)) return (const char*)(p.in + (long long)(blockIdx.x & 7) * C::IN_PLANE);
     return (const char*)(p.in + (long long)n * C::IN_IMG + (long long)(2 * zp + k) * C::IN_PLANE + (4 * yp) * C::IN_ROW + cc * 32);
   };
-  // this wave's PPW of a plane slab's DMA instructions: 16 pixels x 64 B each
-  const int dpix = lane >> 2, dchk = lane & 3;
+  // this wave's PPW of a plane slab's DMA instructions: job j = (slab row j / RPI, 16-pixel part j % RPI), 16 pixels x 64 B
+  // each, to LDS row pitch LP; jobs past the 6 rows (28 x 28 planes: 4 of 16) re-fetch job 0 into the dump area.  The
+  // source is a wave-uniform base + one 32-bit lane offset.
+  const unsigned dlane = (unsigned)((lane >> 2) * (CIN * 2) + (lane & 3) * 16);
   auto dma_plane = [&](const char* src, int k, bool last_touch = false) {
-    if (last_touch) {
-#pragma unroll
-      for (int u = 0; u < C::PPW; ++u) {
-        const int j = wave * C::PPW + u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 16 + dpix) * (CIN * 2) + dchk * 16),
-                                         (__attribute__((address_space(3))) void*)(cp_smem + plane_base(k) + j * 1024), 16, 0, 2 /* nt */);
-      }
-      return;
-    }
 #pragma unroll
     for (int u = 0; u < C::PPW; ++u) {
       const int j = wave * C::PPW + u;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 16 + dpix) * (CIN * 2) + dchk * 16),
-                                       (__attribute__((address_space(3))) void*)(cp_smem + plane_base(k) + j * 1024), 16, 0, RGP_PLANE_AUX);
+      const bool real = j < 6 * C::RPI;
+      const int r = real ? j / C::RPI : 0, q = real ? j - r * C::RPI : 0;
+      const char* g = src + (long long)r * (C::IN_ROW * 2) + q * 16 * (CIN * 2) + dlane;
+      char* l = cp_smem + plane_base(k) + (real ? r * C::LP + q * 1024 : 6 * C::LP + (j - 6 * C::RPI) * 1024);
+      if (last_touch)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 2 /* nt */);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, RGP_PLANE_AUX);
     }
   };
   // filter slab of K step (cc, tap): this wave's BPW of its 1-KB blocks (16 filter rows x 64 B), chunk-swizzled like
@@ -199,35 +220,39 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   // filter row (output channel) behind row brow of 1-KB block blk: blk * 16 + brow, or (!POOL) wave blk / NI, column
   // tile blk % NI: channel 16 NI (blk / NI) + NI brow + blk % NI (rows >= NOUT of a 64-channel filter are the packing's zeros)
   auto b_row = [&](int blk) { return (blk / NI) * (16 * NI) + brow * NI + (blk % NI); };
-  const char* b_src[C::BPW];
+  unsigned b_off[C::BPW];
 #pragma unroll
-  for (int u = 0; u < C::BPW; ++u) b_src[u] = (const char*)(p.wp + (long long)b_row(wave * C::BPW + u) * C::K) + bchk * 16;
+  for (int u = 0; u < C::BPW; ++u) b_off[u] = (unsigned)(b_row(wave * C::BPW + u) * (C::K * 2) + bchk * 16);
   auto dma_b = [&](int slot, int cc, int tap) {
     int koff = (((cc >> 1) * 27 + tap) * 64 + (cc & 1) * 32) * 2;
     if (RGP_CP_ABL(p, 8)) koff = 0;
+    const char* base = (const char*)p.wp + koff;
 #pragma unroll
     for (int u = 0; u < C::BPW; ++u)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[u] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + b_off[u]),
                                        (__attribute__((address_space(3))) void*)(cp_smem + C::BRING_OFF + slot * C::BSLOT + (wave * C::BPW + u) * 1024),
                                        16, 0, 0);
   };
 
-  // fragment addressing.  m-tile i of this wave = pooling windows 2 (7 wm + i), +1; row frow of it: window frow >> 3,
-  // dz = (frow >> 2) & 1, dy = (frow >> 1) & 1, dx = frow & 1; K chunk fk.
-  const int r_ws = frow >> 3, r_dz = (frow >> 2) & 1, r_dy = (frow >> 1) & 1, r_dx = frow & 1;
-  unsigned rowaddr[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int w0 = 2 * (7 * wm + i);
-    const int ypl = w0 / C::XPN, xp = w0 - ypl * C::XPN + r_ws;
-    rowaddr[i] = lds0 + ((2 * ypl + r_dy) * C::WP + 2 * xp + r_dx) * 64 + fk * 16;
+  // fragment addressing (header, round 3).  Row frow of a fragment: window frow >> 2 of the column pair -- (pooled row,
+  // column) = (0, 0), (1, 0), (1, 1), (0, 1) -- and (dy, dx) = ((frow >> 1) & 1, frow & 1); K chunk fk.  Column pair cp of the
+  // tile (0 .. XPN / 2 - 1): accumulator slot i < 4 holds plane dz = wmm of pair 7 wmh + 3 wmm + i, slot i >= 4 plane 1 - wmm
+  // of pair 7 wmh + 4 wmm + i - 4.  ra_lo / ra_hi: this lane's row of the first pair of either set, in the plane its dz reads
+  // for the CURRENT tap group; advanced by one plane per tap group, taken back by two at the end of a sweep.
+  const int r_w = frow >> 2, r_ypl = (r_w == 1 || r_w == 2) ? 1 : 0, r_xo = r_w >> 1;
+  const int r_dy = (frow >> 1) & 1, r_dx = frow & 1;
+  auto pair_of = [&](int i) { return 7 * wmh + (i < 4 ? 3 * wmm + i : 4 * wmm + i - 4); };
+  unsigned ra_lo, ra_hi;
+  {
+    const unsigned base = lds0 + (2 * r_ypl + r_dy) * C::LP + (2 * r_xo + r_dx) * 64 + fk * 16;
+    ra_lo = base + (7 * wmh + 3 * wmm) * 256 + plane_base(wmm);
+    ra_hi = base + (7 * wmh + 4 * wmm) * 256 + plane_base(1 - wmm);
   }
   const unsigned b_addr = lds0 + C::BRING_OFF + (wn * NI) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
 
-  const int cg = tid % C::CGN;                                // POOL epilogue, store pass: this thread's 8 output channels
-  float b4[NI];                                               // bias of this lane's NI MFMA columns
-#pragma unroll
-  for (int q = 0; q < NI; ++q) b4[q] = DGRAD ? 0.f : p.bias[wn * (16 * NI) + frow * NI + q];
+  // the biases go to LDS once (the epilogues read them from there: nothing epilogue-only stays in registers through the K
+  // loop, and no global load sits in the epilogue, whose wait would also drain the look-ahead DMA)
+  if constexpr (!DGRAD) { if (tid < NOUT) ((float*)(cp_smem + C::BIAS_OFF))[tid] = p.bias[tid]; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -257,13 +282,11 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     if (group_b) __builtin_amdgcn_s_barrier();               // run one half-step behind group A
 
     // one group of 9 taps (ky, kx) of plane offset kz, K steps s0 .. s0 + 8 of the tile; NPL plane fetches (PPW
-    // instructions per wave each) are issued in its first LOAD phase
-    auto tap_group = [&](auto NPL_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb, bool odd_sweep = false) {
-      constexpr int NPL = decltype(NPL_)::value;
-      unsigned ra[7];
-      const unsigned pb = r_dz ? plane_base(kz + 1) : plane_base(kz);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) ra[i] = rowaddr[i] + pb;
+    // instructions per wave each) are issued in its first LOAD phase.  MODE 0: all 7 accumulator slots; 1: only slots
+    // 4 .. 6 (the first four multiply a halo plane in this tap group); 2: only slots 0 .. 3
+    auto tap_group = [&](auto NPL_, auto MODE_, int cc, int kz, const char* pl_a, int ka, const char* pl_b, int kb, bool odd_sweep) {
+      constexpr int NPL = decltype(NPL_)::value, MODE = decltype(MODE_)::value;
+      constexpr int I0 = MODE == 1 ? 4 : 0, I1 = MODE == 2 ? 4 : 7;
       const int s0 = cc * 27 + kz * 9;
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
@@ -273,9 +296,18 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
         const unsigned bb = b_addr + slot * C::BSLOT;
         auto reads = [&](auto T9) {
           constexpr int t = decltype(T9)::value;
-          constexpr int imm = ((t / 3) * C::WP + (t % 3)) * 64;
-#pragma unroll
-          for (int i = 0; i < 7; ++i) af[i] = cp_lds_read128<imm>(ra[i]);
+          constexpr int imm = (t / 3) * C::LP + (t % 3) * 64;
+          if constexpr (I0 < 4) {
+            af[0] = cp_lds_read128<imm>(ra_lo);
+            af[1] = cp_lds_read128<imm + 256>(ra_lo);
+            af[2] = cp_lds_read128<imm + 512>(ra_lo);
+            af[3] = cp_lds_read128<imm + 768>(ra_lo);
+          }
+          if constexpr (I1 > 4) {
+            af[4] = cp_lds_read128<imm>(ra_hi);
+            af[5] = cp_lds_read128<imm + 256>(ra_hi);
+            af[6] = cp_lds_read128<imm + 512>(ra_hi);
+          }
         };
         switch (t9) {
           case 0: reads(std::integral_constant<int, 0>{}); break;
@@ -313,7 +345,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
         if (t9 < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C::BPW + NPL * C::PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C::BPW) : "memory");
 #pragma unroll
-        for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(af[i]));
+        for (int i = I0; i < I1; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
         for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(bf[j]));
         __builtin_amdgcn_sched_barrier(0);
@@ -321,26 +353,30 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- COMPUTE ----------------
         __builtin_amdgcn_s_setprio(1);
-#if RGP_MMA_ORDER == 1
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-          for (int i = 0; i < 7; ++i) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
-#else
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
-#endif
+          for (int i = I0; i < I1; ++i) Mma<bf16_t>::step(acc[i][j], af[i], bf[j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 == C::NSLOT ? 0 : slot + 1;
       }
+      // next tap group: one plane further (after kz = 2: back to the planes of kz = 0)
+      ra_lo += kz == 2 ? (unsigned)(-2 * C::PLANE_STRIDE) : (unsigned)C::PLANE_STRIDE;
+      ra_hi += kz == 2 ? (unsigned)(-2 * C::PLANE_STRIDE) : (unsigned)C::PLANE_STRIDE;
     };
+    using I0_ = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
+    const int tn = tile / C::TILES_PER_WINDOW, tr = tile - tn * C::TILES_PER_WINDOW;
+    const int zp = tr / C::YT, yp = tr - zp * C::YT;
+    // this wave's skip mode: in the first pooled plane its dz = 0 slots (0 .. 3 of wave wmm = 0, 4 .. 6 of wmm = 1) idle
+    // through the kz = 0 tap groups, in the last one its dz = 1 slots through kz = 2
+    int mode_k0 = zp == 0 ? (wmm == 0 ? 1 : 2) : 0;
+    int mode_k2 = zp == DEPTH / 2 - 1 ? (wmm == 0 ? 2 : 1) : 0;
+    if (RGP_CP_ABL(p, 16)) mode_k0 = mode_k2 = 0;              // dev: the layout without skipping
 #pragma clang loop unroll(disable)
     for (int cc = 0; cc < C::NCC; ++cc) {
       // the sweep after this one: the next channel slice of this tile, or the first one of the next tile
@@ -352,66 +388,130 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
       // leaves more of the L2 to the filter and to the neighbouring tiles' rows: conv2a -3.5 %, conv3b -0.5 %; conv3a
       // (CIN = 128) measured +0.5 % and the input gradients were not measured: both stay without it.
       constexpr bool LT = !DGRAD && CIN != 128;
-      tap_group(I2{}, cc, 0, plane_src(tile, cc, 2), 2, plane_src(tile, cc, 3), 3, LT && (cc & 1) != 0);
-      tap_group(I1{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0, LT && (ncc & 1) != 0);
-      tap_group(I1{}, cc, 2, plane_src(ntile, ncc, 1), 1, nullptr, 0, LT && (ncc & 1) != 0);
+      const char* p2 = plane_src(tile, cc, 2);
+      const char* p3 = plane_src(tile, cc, 3);
+      const bool lt0 = LT && (cc & 1) != 0, lt1 = LT && (ncc & 1) != 0;
+      if (mode_k0 == 0) tap_group(I2{}, I0_{}, cc, 0, p2, 2, p3, 3, lt0);
+      else if (mode_k0 == 1) tap_group(I2{}, I1{}, cc, 0, p2, 2, p3, 3, lt0);
+      else tap_group(I2{}, I2{}, cc, 0, p2, 2, p3, 3, lt0);
+      tap_group(I1{}, I0_{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0, lt1);
+      const char* n1 = plane_src(ntile, ncc, 1);
+      if (mode_k2 == 0) tap_group(I1{}, I0_{}, cc, 2, n1, 1, nullptr, 0, lt1);
+      else if (mode_k2 == 1) tap_group(I1{}, I1{}, cc, 2, n1, 1, nullptr, 0, lt1);
+      else tap_group(I1{}, I2{}, cc, 2, n1, 1, nullptr, 0, lt1);
     }
     if (!group_b) __builtin_amdgcn_s_barrier();               // the groups are level again
 
-    const int tn = tile / C::TILES_PER_WINDOW, tr = tile - tn * C::TILES_PER_WINDOW;
-    const int zp = tr / C::YT, yp = tr - zp * C::YT;
+    // Epilogue-only lane values are re-derived HERE, per tile, from opaque copies of the lane ids: left visible, the
+    // compiler hoists them (staging offsets, window coordinates, ...) out of the tile loop and then spills them across the
+    // K loop -- and a scratch reload in the epilogue waits on vmcnt(0), i.e. for the whole look-ahead DMA.
+    int e_fk = fk, e_frow = frow, e_tid = tid;
+    asm volatile("" : "+v"(e_fk), "+v"(e_frow), "+v"(e_tid));
+    // this lane's window of accumulator slot i: column pair pair_of(i), member fk -> pooled row ypl, column xp
+    auto lane_window = [&](int i, int& ypl, int& xp) {
+      ypl = (e_fk == 1 || e_fk == 2) ? 1 : 0;
+      xp = 2 * pair_of(i) + (e_fk >> 1);
+    };
+    float b4[NI];                                             // bias of this lane's NI MFMA columns
+#pragma unroll
+    for (int q = 0; q < NI; ++q) b4[q] = DGRAD ? 0.f : ((const float*)(cp_smem + C::BIAS_OFF))[wn * (16 * NI) + e_frow * NI + q];
+    const int cg = e_tid % C::CGN;                            // POOL epilogue, store pass: this thread's 8 output channels
     if (RGP_CP_ABL(p, 2)) {
 #pragma unroll
       for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else if constexpr (POOL) {
-      // ---- epilogue: pool in registers (a lane holds the 4 members of a window with its dz, lane ^ 16 the other 4),
-      // bias + ReLU, pooled bf16 tile (and arg-max codes) through LDS, 16-byte (8-byte) stores ----
+      // ---- epilogue: pool in registers -- max over (dy, dx) = the four registers of an accumulator, max over dz = two
+      // accumulator slots of this wave (column pair 3 of a wave pair: one slot here, one in the other wave, exchanged in
+      // fp32 through the idle ring slot) -- then bias + ReLU, pooled bf16 tile (and arg-max codes dz 4 + dy 2 + dx, first
+      // maximum) through LDS, 16-byte (8-byte) stores ----
       bf16_t* stg = (bf16_t*)(cp_smem + C::STG_OFF);
       unsigned char* stga = (unsigned char*)(cp_smem + C::STGA_OFF);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        // MFMA column frow of n-tile j carries channel 64 wn + 4 frow + j (b_row): the lane's four pooled values of a
-        // window are adjacent channels -- one 8-byte LDS write (one 4-byte write of codes) instead of four 2-byte ones
-        unsigned short pv[4];
-        unsigned pc = 0;
+      float* xm = (float*)(cp_smem + C::BRING_OFF + ((slot + C::AHEAD) & (C::NSLOT - 1)) * C::BSLOT);   // idle until the next LOAD phase
+      unsigned* xi = (unsigned*)(xm + C::WMW / 2 * C::WNW * 4 * 64);
+      // maxima over (dy, dx) of accumulator slot i (and, ARGMAX, the member indices dy 2 + dx, 8 bits per n-tile) -- computed
+      // slot by slot, right before use: all seven at once would pull the 112 accumulators through the vector registers
+      auto pool_slot = [&](int i, float (&m)[4], unsigned& mi) {
+        mi = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 c = acc[i][j];
           if constexpr (ARGMAX) {
             float best = c[0];
-            int idx = 0;
+            unsigned idx = 0;
             if (c[1] > best) { best = c[1]; idx = 1; }
             if (c[2] > best) { best = c[2]; idx = 2; }
             if (c[3] > best) { best = c[3]; idx = 3; }
-            const float ob = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, best), 0x401F));   // lane ^ 16
-            const int oi = __builtin_amdgcn_ds_swizzle(idx, 0x401F);
-            // this lane: dz = 0 (members 0 .. 3), the other: dz = 1
-            pv[j] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
-            pc |= (unsigned)(ob > best ? oi + 4 : idx) << (8 * j);
+            m[j] = best;
+            mi |= idx << (8 * j);
           } else {
-            const float x = cp_max(cp_max3(c[0], c[1], c[2]), c[3]);
-            const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-            pv[j] = f2bf(cp_relu(cp_max(x, y) + b4[j]));
+            m[j] = cp_max(cp_max3(c[0], c[1], c[2]), c[3]);
           }
         }
-        if ((fk & 1) == 0) {
-          const int so = (2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + 4 * frow;
-          uint2 o;
-          o.x = (unsigned)pv[0] | ((unsigned)pv[1] << 16);
-          o.y = (unsigned)pv[2] | ((unsigned)pv[3] << 16);
-          *(uint2*)(stg + so) = o;
-          if constexpr (ARGMAX) *(unsigned*)(stga + so) = pc;
+      };
+      // v0 / i0: the dz = 0 maxima (and member indices) of a slot's window, v1 / i1: dz = 1; stage the lane's 4 channels
+      auto put = [&](int slot_i, const float (&v0)[4], unsigned i0, const float (&v1)[4], unsigned i1) {
+        int ypl, xp;
+        lane_window(slot_i, ypl, xp);
+        const int so = (ypl * C::XPN + xp) * C::STG_LD + wn * 64 + 4 * e_frow;
+        unsigned short pv[4];
+        unsigned pc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool hi = v1[j] > v0[j];
+          pv[j] = f2bf(cp_relu((hi ? v1[j] : v0[j]) + b4[j]));
+          if constexpr (ARGMAX) pc |= (hi ? ((i1 >> (8 * j)) & 0xffu) + 4u : ((i0 >> (8 * j)) & 0xffu)) << (8 * j);
         }
+        uint2 o;
+        o.x = (unsigned)pv[0] | ((unsigned)pv[1] << 16);
+        o.y = (unsigned)pv[2] | ((unsigned)pv[3] << 16);
+        *(uint2*)(stg + so) = o;
+        if constexpr (ARGMAX) *(unsigned*)(stga + so) = pc;
+      };
+      const int xo = ((wmh * C::WNW + wn) * 4 + e_fk) * 64 + 4 * e_frow;   // exchange slot of (wave pair, wn, window fk)
+      float m3[4];                                            // wave wmm = 0: its dz = 0 half of column pair 3, kept for the second pass
+      unsigned mi3 = 0;
+      if (wmm == 0) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          float a0[4], a1[4];
+          unsigned i0, i1;
+          pool_slot(f, a0, i0);
+          pool_slot(f + 4, a1, i1);
+          put(f, a0, i0, a1, i1);
+        }
+        pool_slot(3, m3, mi3);
+      } else {
+#pragma unroll
+        for (int f = 4; f < 7; ++f) {
+          float a0[4], a1[4];
+          unsigned i0, i1;
+          pool_slot(f, a0, i0);
+          pool_slot(f - 3, a1, i1);
+          put(f, a0, i0, a1, i1);
+        }
+        // dz = 1 half of column pair 3 (slot 0 here) for wave wmm = 0 of the pair
+        pool_slot(0, m3, mi3);
+        *(f32x4*)(xm + xo) = (f32x4){m3[0], m3[1], m3[2], m3[3]};
+        if constexpr (ARGMAX) xi[xo >> 2] = mi3;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
+      __builtin_amdgcn_s_barrier();
+      if (wmm == 0) {
+        const f32x4 q = *(const f32x4*)(xm + xo);
+        const float v1[4] = {q[0], q[1], q[2], q[3]};
+        unsigned i1 = 0;
+        if constexpr (ARGMAX) i1 = xi[xo >> 2];
+        put(3, m3, mi3, v1, i1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
       unsigned char* abase = ARGMAX ? p.argmax + (((long long)tn * (DEPTH / 2) + zp) * (HW / 2) + 2 * yp) * (long long)((HW / 2) * NOUT) : nullptr;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int w = tid / C::CGN + (512 / C::CGN) * k;      // pooling window of the tile
+        const int w = e_tid / C::CGN + (512 / C::CGN) * k;    // pooling window of the tile
         if (w < C::WIN && !RGP_CP_ABL(p, 4)) {
           const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
           *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = *(const u32x4*)(stg + w * C::STG_LD + cg * 8);
@@ -419,18 +519,19 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
         }
       }
     } else {
-      // ---- epilogue: bias + ReLU, 8-byte stores from registers.  Register e of accumulator (i, j): row 4 fk + e of
-      // m-tile i = window 2 (7 wm + i) + (fk >> 1), dz = fk & 1, dy = e >> 1, dx = e & 1; channel 64 wn + 4 frow + j ----
-      // position of (window w, dz, dy, dx): halo-padded image, or (DENSE) natural (z, y, x) order without halo
+      // ---- epilogue: bias + ReLU, 8-byte stores from registers.  Accumulator slot i, register e: this lane's window of
+      // the slot's column pair, plane dz of the slot, dy = e >> 1, dx = e & 1; channels 16 NI wn + NI frow + 0 .. NI-1 ----
+      // position of (window, dz, dy, dx): halo-padded image, or (DENSE) natural (z, y, x) order without halo
       constexpr int ROWS = DENSE ? HW * NOUT : C::OUT_ROW, PLANES = DENSE ? HW * ROWS : C::OUT_PLANE;
       constexpr long long IMG = DENSE ? (long long)DEPTH * PLANES : (long long)C::OUT_IMG;
       constexpr int H1 = DENSE ? 0 : 1;
-      const long long obase = (long long)tn * IMG + (2 * zp + H1 + (fk & 1)) * PLANES + (4 * yp + H1) * ROWS + H1 * NOUT + wn * (16 * NI) + frow * NI;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        const int w = 2 * (7 * wm + i) + (fk >> 1);
-        const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
-        const long long ow = obase + (2 * ypl) * ROWS + (2 * xp) * NOUT;
+        int ypl, xp;
+        lane_window(i, ypl, xp);
+        const int dz = i < 4 ? wmm : 1 - wmm;
+        const long long ow = (long long)tn * IMG + (2 * zp + H1 + dz) * PLANES + (4 * yp + 2 * ypl + H1) * ROWS + (2 * xp + H1) * NOUT +
+                             wn * (16 * NI) + e_frow * NI;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const long long oe = ow + (e >> 1) * ROWS + (e & 1) * NOUT;
@@ -438,12 +539,12 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #pragma unroll
           for (int j = 0; j < NI; ++j) v[j] = DGRAD ? acc[i][j][e] : fmaxf(acc[i][j][e] + b4[j], 0.f);
           if constexpr (DGRAD && !DENSE) {
-            unsigned m[NI / 2];
-            if constexpr (NI == 4) { const uint2 mm = *(const uint2*)(p.mask + oe); m[0] = mm.x; m[1] = mm.y; }
-            else m[0] = *(const unsigned*)(p.mask + oe);
+            unsigned mk[NI / 2];
+            if constexpr (NI == 4) { const uint2 mm = *(const uint2*)(p.mask + oe); mk[0] = mm.x; mk[1] = mm.y; }
+            else mk[0] = *(const unsigned*)(p.mask + oe);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-              if (!(bf2f((bf16_t)((m[j >> 1] >> (16 * (j & 1))) & 0xffffu)) > 0.f)) v[j] = 0.f;
+              if (!(bf2f((bf16_t)((mk[j >> 1] >> (16 * (j & 1))) & 0xffffu)) > 0.f)) v[j] = 0.f;
           }
           if constexpr (NI == 4) {
             uint2 o;

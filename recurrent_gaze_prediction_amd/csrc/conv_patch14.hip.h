@@ -51,7 +51,8 @@ template <int CIN, bool POOL, int NOUT_ = 512> struct Patch14Cfg {
   static constexpr int STG_OFF = BRING_OFF + NSLOT * BSLOT;
   static constexpr int WIN = 28, STG_LD = TN + 8;
   static constexpr int STGA_OFF = STG_OFF + WIN * STG_LD * 2;
-  static constexpr int SMEM = POOL ? STGA_OFF + WIN * STG_LD : STG_OFF;     // 162 464 / 140 288
+  static constexpr int BIAS_OFF = POOL ? STGA_OFF : STG_OFF;   // inference kernels: the 512 biases (pooled: over the unused arg-max code area)
+  static constexpr int SMEM = POOL ? STGA_OFF + WIN * STG_LD : STG_OFF + NOUT * 4;     // 162 464 / 142 336
   static constexpr int NSTEP = NCC * 27;
   static constexpr int K = 27 * CIN;
   static constexpr int IN_ROW = 16 * CIN, IN_PLANE = 16 * IN_ROW, IN_IMG = 6 * IN_PLANE;                 // elements
@@ -171,7 +172,10 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
     ra_hi = base + (4 * wm) * 128 + plane_base(1 - wm);
   }
   const unsigned b_addr = lds0 + C::BRING_OFF + (wn * 4) * 1024 + frow * 64 + ((fk ^ ((-(frow >> 2)) & 3)) << 4);
-  const int cg = tid % C::CGN;
+  // inference kernels keep the 512 biases in LDS (the arg-max code area is unused there): the epilogue reads them with a
+  // ds_read; a global load there waits on vmcnt(0), i.e. for the whole look-ahead DMA.  Training kernels load them per tile.
+  constexpr bool BIAS_LDS = !DGRAD && !ARGMAX;
+  if constexpr (BIAS_LDS) { if (tid < C::NOUT) ((float*)(cq_smem + C::BIAS_OFF))[tid] = p.bias[tid]; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- prologue (once) ----
@@ -318,11 +322,18 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
     }
     if (!group_b) __builtin_amdgcn_s_barrier();               // the groups are level again
 
-    // bias of this lane's 4 MFMA columns in this column tile: fetched here (the wait for it also drains the 3 look-ahead
-    // slabs, once per tile) rather than held in 8 registers through the K loop
+    // Epilogue-only lane values are re-derived here, per tile, from opaque copies of the lane ids (left visible, the compiler
+    // hoists staging offsets and window coordinates out of the tile loop and spills them across the K loop; a scratch reload
+    // in the epilogue waits on vmcnt(0)).
+    int e_fk = fk, e_frow = frow, e_tid = tid;
+    asm volatile("" : "+v"(e_fk), "+v"(e_frow), "+v"(e_tid));
+    // bias of this lane's 4 MFMA columns in this column tile
     float b4[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b4[q] = DGRAD ? 0.f : p.bias[ct * C::TN + (POOL ? wn * 64 + q * 16 + frow : wn * 64 + frow * 4 + q)];
+    for (int q = 0; q < 4; ++q) {
+      const int ch = ct * C::TN + (POOL ? wn * 64 + q * 16 + e_frow : wn * 64 + e_frow * 4 + q);
+      b4[q] = DGRAD ? 0.f : BIAS_LDS ? ((const float*)(cq_smem + C::BIAS_OFF))[ch] : p.bias[ch];
+    }
     if constexpr (POOL) {
       // ---- epilogue: pool in registers -- max over (dy, dx) = the four registers, max over dz = two accumulator slots of
       // this wave (fragment 3: one slot here, one in the other M wave, exchanged in fp32 through the idle ring slot) --
@@ -349,8 +360,8 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
       // staging position of (fragment f, this lane's window fk, column j 16 + frow)
       auto stage_pos = [&](int f, int j) {
         int u, xp;
-        frag_window(f, fk, u, xp);
-        return (u * 7 + xp) * C::STG_LD + wn * 64 + j * 16 + frow;
+        frag_window(f, e_fk, u, xp);
+        return (u * 7 + xp) * C::STG_LD + wn * 64 + j * 16 + e_frow;
       };
       auto put = [&](int f, int j, float v0, int i0, float v1, int i1) {      // v0: dz = 0 maximum, v1: dz = 1
         const int so = stage_pos(f, j);
@@ -371,8 +382,8 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
         // dz = 1 half of fragment 3 (slot 0 here) for M wave 0: [window fk][column] fp32 + index byte
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          xm[fk * 256 + wn * 64 + j * 16 + frow] = m[0][j];
-          if constexpr (ARGMAX) xi[fk * 256 + wn * 64 + j * 16 + frow] = (unsigned char)mi[0][j];
+          xm[e_fk * 256 + wn * 64 + j * 16 + e_frow] = m[0][j];
+          if constexpr (ARGMAX) xi[e_fk * 256 + wn * 64 + j * 16 + e_frow] = (unsigned char)mi[0][j];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
@@ -380,17 +391,18 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
       if (wm == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float v1 = xm[fk * 256 + wn * 64 + j * 16 + frow];
+          const float v1 = xm[e_fk * 256 + wn * 64 + j * 16 + e_frow];
           int i1 = 0;
-          if constexpr (ARGMAX) i1 = xi[fk * 256 + wn * 64 + j * 16 + frow];
+          if constexpr (ARGMAX) i1 = xi[e_fk * 256 + wn * 64 + j * 16 + e_frow];
           put(3, j, m[3][j], mi[3][j], v1, i1);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      const int cg = e_tid % C::CGN;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int w = tid / C::CGN + (512 / C::CGN) * k;      // window of the tile: slot u = w / 7, column xp = w % 7
+        const int w = e_tid / C::CGN + (512 / C::CGN) * k;      // window of the tile: slot u = w / 7, column xp = w % 7
         if (w < C::WIN) {
           const int u = w / 7, xp = w - u * 7;
           const Slot sl = slot_of(bt, u);
@@ -410,7 +422,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         int u, xp;
-        frag_window(frag_of(i), fk, u, xp);
+        frag_window(frag_of(i), e_fk, u, xp);
         const Slot sl = slot_of(bt, u);
         const int dz = i < 4 ? wm : 1 - wm;
         if (sl.valid) {
@@ -419,7 +431,7 @@ static __global__ __launch_bounds__(512) void conv_patch14_bf16_kernel(const Con
           constexpr long long IMG = DENSE ? 4LL * PLANES : (long long)C::OUT_IMG;
           constexpr int H1 = DENSE ? 0 : 1;
           const long long ow = (long long)sl.n * IMG + (2 * sl.zp + dz + H1) * PLANES + (2 * sl.yp + H1) * ROWS + (2 * xp + H1) * C::NOUT +
-                               ct * C::TN + wn * 64 + frow * 4;
+                               ct * C::TN + wn * 64 + e_frow * 4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const long long oe = ow + (e >> 1) * ROWS + (e & 1) * C::NOUT;
