@@ -377,6 +377,9 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     int mode_k0 = zp == 0 ? (wmm == 0 ? 1 : 2) : 0;
     int mode_k2 = zp == DEPTH / 2 - 1 ? (wmm == 0 ? 2 : 1) : 0;
     if (RGP_CP_ABL(p, 16)) mode_k0 = mode_k2 = 0;              // dev: the layout without skipping
+    // conv3b's training forward (arg-max codes): with the three loop variants the register allocator spills a fragment
+    // inside the COMPUTE phases (scripts/check_isa_waits.py); it runs all seven slots in every tap group
+    if constexpr (ARGMAX && CIN == 256) mode_k0 = mode_k2 = 0;
 #pragma clang loop unroll(disable)
     for (int cc = 0; cc < C::NCC; ++cc) {
       // the sweep after this one: the next channel slice of this tile, or the first one of the next tile

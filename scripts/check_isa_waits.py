@@ -69,8 +69,46 @@ def wgrad_patch_faults(body):
     return faults
 
 
+def patch_kernels(asm):
+    lines = asm.split('\n')
+    for st, l in enumerate(lines):
+        if l.startswith('_ZN3rgpL') and 'conv_patch' in l and '@' in l:
+            end = next(i for i in range(st, len(lines)) if 's_endpgm' in lines[i])
+            yield l.split(':')[0], lines[st:end]
+
+
+def patch_faults(name, body):
+    """conv_patch*.hip.h: no scratch access between the first and the last MFMA (a reload there waits on vmcnt and with it
+    on the LDS-DMA ring), and -- inference kernels (no arg-max codes) -- none behind the last MFMA either: the round-3
+    kernels lost 2-4 % to epilogue-only values the compiler had hoisted out of the tile loop and spilled across the K loop
+    (each reload drained the look-ahead DMA once per tile)."""
+    mf = [i for i, l in enumerate(body) if 'v_mfma' in l]
+    sc = [i for i, l in enumerate(body) if 'scratch_load' in l]
+    faults = []
+    if any(mf[0] <= i <= mf[-1] for i in sc):
+        faults.append('scratch reload inside the MFMA region')
+    training = 'Lb1ELb1E' in name                      # <..., POOL = true, ARGMAX = true, ...>
+    if not training and any(i > mf[-1] for i in sc):
+        faults.append('scratch reload in the epilogue')
+    return faults
+
+
 def main():
     rc = 0
+    with tempfile.NamedTemporaryFile(suffix='.s') as tf:
+        subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
+                        '-I' + CSRC, '-S', '--cuda-device-only', '-o', tf.name, os.path.join(CSRC, 'rgp_conv_patch.hip')], check=True,
+                       stderr=subprocess.DEVNULL)
+        asm = open(tf.name).read()
+    n = nbad = 0
+    for name, body in patch_kernels(asm):
+        n += 1
+        faults = patch_faults(name, body)
+        if faults:
+            nbad += 1
+            print('CONV_PATCH', name[:100], faults)
+    print('rgp_conv_patch.hip: %d patch kernels, %d with scratch reloads in the K loop / an inference epilogue' % (n, nbad))
+    rc |= nbad > 0
     for tu in ('rgp_c3d.hip', 'rgp_c3d_bwd.hip'):
         with tempfile.NamedTemporaryFile(suffix='.s') as tf:
             subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
