@@ -62,6 +62,12 @@
 #ifndef RGP_MMA_ORDER
 #define RGP_MMA_ORDER 1     // 1: filter fragment outermost in a step (7 consecutive MFMAs share it; 0: the activation fragment, 4): -0.5 % wall
 #endif
+#ifndef RGP_CP_CHUNK56
+#define RGP_CP_CHUNK56 1     // clip windows per tile-order chunk, 56 x 56 planes (see decode() in the kernel)
+#endif
+#ifndef RGP_CP_CHUNK28
+#define RGP_CP_CHUNK28 16    // ... 28 x 28 planes (8: conv3b 2 x FETCH 12.8 GB, 16 and 32: 11.1 GB; times equal)
+#endif
 #ifndef RGP_PLANE_AUX
 #define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured)
 #endif
@@ -178,6 +184,21 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
   };
   int t_seq = blockIdx.x;
   if (t_seq >= nt) return;
+  // tile -> (clip window, pooled plane zp, tile row yp).  Tiles are numbered (chunk of RGP_CP_CHUNK56 / 28 windows, zp, window, yp):
+  // runs of CHUNK x YT tiles of ONE pooled plane follow each other, so the CUs of an XCD work on tiles of equal length at
+  // any time -- the tiles of the first / last pooled plane skip tap groups and are ~7 % shorter; mixed with the others
+  // they let the CUs drift apart, which costs the L2 sharing of halo rows and planes between neighbouring tiles
+  // (conv3b's traffic beyond L2 went 9.4 -> 18 GB with the (window, zp, yp) order)
+  auto decode = [&](int tile, int& tn, int& zp, int& yp) {
+    constexpr int NW = HW == 56 ? RGP_CP_CHUNK56 : RGP_CP_CHUNK28, TPW = C::TILES_PER_WINDOW;
+    const int c = tile / (NW * TPW), r = tile - c * (NW * TPW);
+    const int cw = min(NW, p.n_windows - c * NW);              // windows of this chunk (the last one may be short)
+    zp = r / (cw * C::YT);
+    const int r2 = r - zp * (cw * C::YT);
+    const int w = r2 / C::YT;
+    tn = c * NW + w;
+    yp = r2 - w * C::YT;
+  };
 #ifdef RGP_DEV_KNOBS
   // dev experiment (RGP_CP_ABLATE bits 8..15 = n): block i of an XCD starts i * n * 0.43 us late, so that the 32 CUs of an
   // XCD read the filter out of phase (every slab is then re-touched 32 times per tile time instead of once: it stays in
@@ -190,8 +211,8 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 
   // source of plane k of (tile, channel sweep cc)
   auto plane_src = [&](int tile, int cc, int k) -> const char* {
-    const int n = tile / C::TILES_PER_WINDOW, r = tile - n * C::TILES_PER_WINDOW;
-    const int zp = r / C::YT, yp = r - zp * C::YT;
+    int n, zp, yp;
+    decode(tile, n, zp, yp);
     if (RGP_CP_ABL(p, 1)) return (const char*)(p.in + (long long)(blockIdx.x & 7) * C::IN_PLANE);
     return (const char*)(p.in + (long long)n * C::IN_IMG + (long long)(2 * zp + k) * C::IN_PLANE + (4 * yp) * C::IN_ROW + cc * 32);
   };
@@ -370,8 +391,8 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     using I0_ = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    const int tn = tile / C::TILES_PER_WINDOW, tr = tile - tn * C::TILES_PER_WINDOW;
-    const int zp = tr / C::YT, yp = tr - zp * C::YT;
+    int tn, zp, yp;
+    decode(tile, tn, zp, yp);
     // this wave's skip mode: in the first pooled plane its dz = 0 slots (0 .. 3 of wave wmm = 0, 4 .. 6 of wmm = 1) idle
     // through the kz = 0 tap groups, in the last one its dz = 1 slots through kz = 2
     int mode_k0 = zp == 0 ? (wmm == 0 ? 1 : 2) : 0;
@@ -380,6 +401,9 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
     // conv3b's training forward (arg-max codes): with the three loop variants the register allocator spills a fragment
     // inside the COMPUTE phases (scripts/check_isa_waits.py); it runs all seven slots in every tap group
     if constexpr (ARGMAX && CIN == 256) mode_k0 = mode_k2 = 0;
+    // conv2a (56 x 56 planes, 2 of its 8 pooled planes could skip): measured, skipping gains it nothing (14.10 vs 14.20 ms,
+    // both -0.4 % against the round-2 layout) and the unequal tiles let the CUs drift apart: 2 x FETCH 8.2 -> 17.5 GB
+    if constexpr (HW == 56) mode_k0 = mode_k2 = 0;
 #pragma clang loop unroll(disable)
     for (int cc = 0; cc < C::NCC; ++cc) {
       // the sweep after this one: the next channel slice of this tile, or the first one of the next tile
