@@ -17,24 +17,19 @@
 // all 27 taps are read from it at shifted addresses (what conv1a.hip.h does for the first layer):
 //
 //  * tile = 2 pooled rows x 28 pooled columns of one pooled plane of one window = 56 pooling windows = 448 conv
-//    outputs x 128 channels; its input is 4 planes x 6 rows x 58 pixels of act1 [n][18][58][58][64].  A plane slab is
-//    348 consecutive pixels in memory (full rows incl. the x halo); 24 LDS-DMA instructions bring 64 B (one channel
-//    half) of each of 384 pixels into a 24 KB plane buffer.
+//    outputs x 128 channels; its input is 4 planes x 6 rows x 58 pixels of act1 [n][18][58][58][64].  24 LDS-DMA
+//    instructions (4 per slab row, 16 pixels each) bring 64 B (one channel half) of each pixel into a 24 KB plane buffer.
 //  * K order: channel half cc (2) x tap (27, kz-major) x 32 channels.  A K step reads, per wave, 7 A fragments from
-//    the patch at (row base + plane base) + immediate (ky*58 + kx)*64, and 4 B fragments from a ring of 8 KB filter
+//    the patch at (row base + plane base) + immediate (ky pitch + 64 kx), and 4 B fragments from a ring of 8 KB filter
 //    slabs (the packed filter of the general kernel, [128][tap*64 + c]).  L2 -> LDS per step: 8 KB of filter + 96 KB
 //    of patch per 27 steps = 11.6 KB (was 40).
 //  * plane buffers: the rows with dz = 0 read plane kz, those with dz = 1 plane kz + 1, so plane 0 is free after the
 //    kz = 0 taps and plane 1 after kz = 1: the next sweep's planes 0 / 1 are fetched at the start of this sweep's
 //    kz = 1 / kz = 2 tap groups and its planes 2, 3 at the start of its own kz = 0 group -- four buffers, no stall.
-//  * banks: an A-fragment read (ds_read_b128; 16 rows = 2 adjacent pooling windows x (dz,dy,dx), 4 K chunks) touches
-//    runs of 4 consecutive pixels (256 B) on rows whose pitch is 58*64 = 128 (mod 256), and the plane buffers start
-//    at 32 (k & 1) (mod 256): every 16-lane group of the read covers the 64 banks exactly once.  No swizzle.
-//  * rows are ordered (pooling window, dz, dy, dx): a lane's 4 accumulator registers + the lane 16 further hold one
-//    window, pool2 is a max3 tree and one ds_swizzle; the pooled 56 x 128 tile goes through LDS (8-byte writes of 4
-//    adjacent channels per lane) for 16-byte stores.
-//    (The stores sit in the same vmcnt queue as the DMA: the first two counted waits of the next tile also wait for
-//    them -- conservative, never early.)
+//  * banks, row order and pooling: see "Round 3" below (rounds 1-2 ordered the rows (pooling window, dz, dy, dx) on a row
+//    pitch of 128 (mod 256) with the plane buffers 32 bytes apart (mod 256); the pooled 56 x 128 tile still goes through
+//    LDS -- 8-byte writes of 4 adjacent channels per lane -- for 16-byte stores, which sit in the same vmcnt queue as the
+//    DMA: the first two counted waits of the next tile also wait for them -- conservative, never early).
 //  * schedule: the two-group staggered loop of igemm_wide.hip.h (waves 0-3 / 4-7, partners on a SIMD, half a step
 //    apart: LOAD = fragment reads + DMA issue + counted wait, COMPUTE = 28 MFMAs), waves 4 (M) x 2 (N), 112 x 64 each.
 //
@@ -50,7 +45,8 @@
 //    fragment address is one register per dz set + immediates (256 bytes per column pair, ky pitch + 64 kx per tap).
 //  * output plane z = 0 multiplies its kz = 0 taps with the zero halo plane z = -1, and z = DEPTH - 1 its kz = 2 taps with
 //    the halo plane z = DEPTH: in the tiles of the first / last pooled plane the dz = 0 / dz = 1 fragments skip that tap
-//    group (12 or 16 MFMAs per wave and step instead of 28).  2 of 8 (conv2a) / 2 of 4 (conv3a, conv3b) pooled planes.
+//    group (12 or 16 MFMAs per wave and step instead of 28): 2 of the 4 pooled planes of conv3a / conv3b.  conv2a (2 of 8)
+//    measured no gain and runs every tap group; so does conv3b's training forward (register pressure, see the kernel).
 //  * pooling: max over (dy, dx) in the lane's registers, over dz between two accumulator slots of the wave; column pair 3
 //    has its two planes in different waves, which exchange fp32 maxima through the filter-ring slot that is idle during
 //    the epilogue (conv_patch14.hip.h).
