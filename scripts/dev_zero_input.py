@@ -5,6 +5,12 @@ show each kernel's stall-limited time at the full clock.  usage: dev_zero_input.
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('RGP_DEV_LIB'):                         # another build of the library (A/B on one box)
+    import ctypes
+    from recurrent_gaze_prediction_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['RGP_DEV_LIB'])
+    _probe = ctypes.CDLL(_lib.LIB_PATH)
+    _lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_probe, k)}
 import torch
 from recurrent_gaze_prediction_amd import synthetic as syn
 from recurrent_gaze_prediction_amd.engine import C3DEngine
