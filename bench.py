@@ -225,12 +225,24 @@ def main():
             flops = HEAD_FLOPS[kname] * F * args.steps
         achieved = flops / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process.  `traffic` is null
-        # unless this very invocation runs under rocprofv3 --pmc and a wrapper fills it in afterwards
-        # (scripts/pmc_summary.py writes profiles/r02_traffic_dominant_kernel.json from such a run; DESIGN.md quotes it).
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process.  For the default
+        # command the figure comes from the committed summary of separate `rocprofv3 --pmc` passes of this very command
+        # (scripts/r03_profiles.sh -> scripts/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction;
+        # Infinity-Cache hits are counted, so it is traffic beyond L2, an upper bound of HBM bytes); any other invocation
+        # reports null.
         traffic = None
+        if c3d is not None and args.workload == 'e2e' and min(args.c3d_chunk, F) == 1024:
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_summary.json')) as fh:
+                    pmc = json.load(fh)
+                stem = ','.join(kname.replace(' ', '').split(',')[:4])      # kernel<CIN,NOUT,HW,D
+                hit = [v for k, v in pmc.items() if ','.join(k.replace(' ', '').split(',')[:4]) == stem and 'hbm_bytes_per_launch' in v]
+                if len(hit) == 1:
+                    traffic = round(hit[0]['hbm_bytes_per_launch'] / 1e9, 3)      # GB per launch
+            except (OSError, ValueError):
+                traffic = None
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / peak, 4), 'traffic': traffic,
+                    'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'GB per launch',
                     'traffic_profile': 'profiles/r03_pmc_summary.json (separate rocprofv3 --pmc passes of this command)',
                     'kernel': kname,
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
