@@ -6,6 +6,7 @@
 
 #include "rgp_grcn_plan.h"
 #include "convgru_seq.hip.h"
+#include "head_logits.hip.h"
 
 using namespace rgp;
 
@@ -15,36 +16,53 @@ namespace {
 // filter [k,k,Cout,Cin]) (gaze_grcn.py:326-343):
 //   out[s*i+py, s*j+px, o] = sum_{a',b',c} in[i-a', j-b', c] * F[py+s*a', px+s*b', o, c]
 // Input image is halo-padded by hin (>= taps-1), output image by hout.
-bool build_deconv_phases(std::vector<ConvDesc>& out, int k, int s, int H, int hin, int Cin, int OH, int hout, int Cout,
-                         int dtype) {
+// One GEMM per ROW phase py: its s column phases px share their input rows, and the s x Cout values of output pixels
+// s*j .. s*j+s-1 are contiguous in memory, so they are the N = s*Cout columns (px, o) of one problem (round 3; before:
+// s*s launches of N = Cout, each re-gathering the input).  The tap window is the widest phase's (px = 0: tbm taps in
+// x); a phase that lacks a tap gets zero weights for it (pack[]: one tap table per px, -1 = zero).  Rows j beyond a
+// phase's own extent compute positions x >= OH: every input they touch is halo, so exact zeros land in the output halo.
+bool build_deconv_phases(std::vector<ConvDesc>& out, std::vector<ConvDesc>& pack, int k, int s, int H, int hin, int Cin, int OH,
+                         int hout, int Cout, int dtype) {
   const int Wp = H + 2 * hin, OWp = OH + 2 * hout;
-  for (int py = 0; py < s; ++py)
+  const int tbm = (k + s - 1) / s, Wph = (OH + s - 1) / s;
+  if (hin < tbm - 1 || Wph > H + hin || s * (Wph - 1) + s - 1 + hout >= OWp) return false;
+  for (int py = 0; py < s; ++py) {
+    const int ta = (k - py + s - 1) / s;
+    const int Hph = (OH - py + s - 1) / s;
+    if (hin < ta - 1 || Hph > H + hin) return false;
+    ConvDesc d;
+    d.Mw = Hph * Wph;
+    d.N = s * Cout;
+    d.in_img_stride = (long long)Wp * Wp * Cin;
+    d.out_img_stride = (long long)OWp * OWp * Cout;
+    for (int i = 0; i < Hph; ++i)
+      for (int j = 0; j < Wph; ++j) {
+        d.in_tab.push_back(((i - (ta - 1) + hin) * Wp + (j - (tbm - 1) + hin)) * Cin);
+        d.out_tab.push_back(((s * i + py + hout) * OWp + (s * j + hout)) * Cout);
+      }
+    std::vector<int> tapoff, fidx;
+    for (int u = 0; u < ta; ++u)
+      for (int v = 0; v < tbm; ++v) {
+        tapoff.push_back((u * Wp + v) * Cin);
+        fidx.push_back((py + s * (ta - 1 - u)) * k + s * (tbm - 1 - v));
+      }
+    if (!build_k_schedule(d, tapoff, fidx, Cin, dtype)) return false;
+    d.s_tap = (long long)Cout * Cin;
+    d.s_n = Cin;
+    d.s_c = 1;
+    // packing aliases: rows px*Cout .. of the same packed filter, taps shifted by px (beyond the filter: zero)
     for (int px = 0; px < s; ++px) {
-      const int ta = (k - py + s - 1) / s, tb = (k - px + s - 1) / s;
-      const int Hph = (OH - py + s - 1) / s, Wph = (OH - px + s - 1) / s;
-      if (hin < ta - 1 || hin < tb - 1 || Hph > H + hin || Wph > H + hin) return false;
-      ConvDesc d;
-      d.Mw = Hph * Wph;
-      d.N = Cout;
-      d.in_img_stride = (long long)Wp * Wp * Cin;
-      d.out_img_stride = (long long)OWp * OWp * Cout;
-      for (int i = 0; i < Hph; ++i)
-        for (int j = 0; j < Wph; ++j) {
-          d.in_tab.push_back(((i - (ta - 1) + hin) * Wp + (j - (tb - 1) + hin)) * Cin);
-          d.out_tab.push_back(((s * i + py + hout) * OWp + (s * j + px + hout)) * Cout);
-        }
-      std::vector<int> tapoff, fidx;
-      for (int u = 0; u < ta; ++u)
-        for (int v = 0; v < tb; ++v) {
-          tapoff.push_back((u * Wp + v) * Cin);
-          fidx.push_back((py + s * (ta - 1 - u)) * k + (px + s * (tb - 1 - v)));
-        }
-      if (!build_k_schedule(d, tapoff, fidx, Cin, dtype)) return false;
-      d.s_tap = (long long)Cout * Cin;
-      d.s_n = Cin;
-      d.s_c = 1;
-      out.push_back(d);
+      ConvDesc a = d;
+      a.in_tab.clear(); a.out_tab.clear(); a.koff.clear(); a.koff_tm.clear();
+      for (size_t t = 0; t < a.tap_src.size(); ++t) {
+        if (t >= fidx.size() || a.tap_src[t] < 0) { a.tap_src[t] = -1; continue; }
+        const int kx = fidx[t] % k + px;
+        a.tap_src[t] = kx < k ? fidx[t] + px : -1;
+      }
+      pack.push_back(a);
     }
+    out.push_back(d);
+  }
   return true;
 }
 
@@ -65,6 +83,9 @@ size_t put_tab(Arena& a, const std::vector<int>& t) { return a.take(t.size() * 4
 // useful, 5x less MFMA work than before.  49 = 3 x 16 + 1: the last pixel column goes through the 1-column path.
 template <typename T, int G>
 int run_d3(rgp_grcn* g, float* logits, hipStream_t s) {
+  if constexpr (sizeof(T) == 2)                                // bf16: the band kernel (head_logits.hip.h), all 49 columns
+    return run_head_logits((const bf16_t*)(g->ws + g->D2.off), (const bf16_t*)(g->ws + g->d3t.w_off),
+                           (const float*)(g->ws + g->bias16.off), logits, g->F, s);
   {
     IgemmParams p = make_params(g->d3t, g->ws + g->D2.off, g->ws, g->F);
     EpiParams e = make_epi(g->d3t, logits, g->ws);
@@ -228,12 +249,8 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_TRY(pk.add(g->gzr, w->gru_Uz, S, 0));
   RGP_TRY(pk.add(g->gzr, w->gru_Ur, S, S));
   RGP_TRY(pk.add(g->gc, w->gru_U, S, 0));
-  for (ConvDesc& d : g->d1) {
-    RGP_TRY(pk.add(d, w->up_weight1, 64, 0));
-  }
-  for (ConvDesc& d : g->d2) {
-    RGP_TRY(pk.add(d, w->up_weight2, 32, 0));
-  }
+  for (size_t i = 0; i < g->d1_pack.size(); ++i) RGP_TRY(pk.add(g->d1_pack[i], w->up_weight1, 64, (int)(i % 3) * 64));   // column phase px = i % 3
+  for (size_t i = 0; i < g->d2_pack.size(); ++i) RGP_TRY(pk.add(g->d2_pack[i], w->up_weight2, 32, (int)(i % 2) * 32));
   float* gf = (float*)(ws + g->gfold.off);
   fold_head_filter_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(w->up_weight3, w->out_W, gf, 49, 12, 32);
   RGP_HIP(hipGetLastError());
@@ -321,8 +338,8 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   ok &= conv3x3(g->gc, S, S);
   g->gc.out_tab = pad_tab(7, 1, S); g->gc.out_img_stride = 81LL * S;
 
-  ok &= build_deconv_phases(g->d1, 5, 3, 7, 1, S, 23, 2, 64, dtype);    // gaze_grcn.py:326-333
-  ok &= build_deconv_phases(g->d2, 5, 2, 23, 2, 64, 49, 3, 32, dtype);  // gaze_grcn.py:336-343
+  ok &= build_deconv_phases(g->d1, g->d1_pack, 5, 3, 7, 1, S, 23, 2, 64, dtype);    // gaze_grcn.py:326-333
+  ok &= build_deconv_phases(g->d2, g->d2_pack, 5, 2, 23, 2, 64, 49, 3, 32, dtype);  // gaze_grcn.py:336-343
 
   // 7x7 SAME stride-1 transposed conv folded with the 12->1 projection
   // (gaze_grcn.py:353-361): logit[y,x] = sum in[y-a+3, x-b+3, c] G[a,b,c] + out_b.
@@ -350,6 +367,19 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3, &g->d3t}) d->reserve(a, dtype);
   for (ConvDesc& d : g->d1) d.reserve(a, dtype);
   for (ConvDesc& d : g->d2) d.reserve(a, dtype);
+  // packing aliases: a tap table of their own, the packed filter of the problem they belong to
+  auto reserve_aliases = [&](std::vector<ConvDesc>& al, const std::vector<ConvDesc>& ds) {
+    const size_t per = al.size() / ds.size();
+    for (size_t i = 0; i < al.size(); ++i) {
+      const int n = al[i].N;
+      al[i].N = 0;                                             // (no filter area of its own)
+      al[i].reserve(a, dtype);
+      al[i].N = n;
+      al[i].w_off = ds[i / per].w_off;
+    }
+  };
+  reserve_aliases(g->d1_pack, g->d1);
+  reserve_aliases(g->d2_pack, g->d2);
   g->tab_pad9_P = pad_tab(7, 1, P); g->o_pad9_P = put_tab(a, g->tab_pad9_P);
   g->tab_pad9_S = pad_tab(7, 1, S); g->o_pad9_S = put_tab(a, g->tab_pad9_S);
   g->tab_pad27 = pad_tab(23, 2, 64); g->o_pad27 = put_tab(a, g->tab_pad27);
@@ -434,6 +464,8 @@ int rgp_grcn_bind_workspace(rgp_grcn_t* g, void* workspace, size_t bytes, rgp_st
   for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3, &g->d3t}) RGP_TRY(upload_desc(*d, g->ws, s));
   for (ConvDesc& d : g->d1) RGP_TRY(upload_desc(d, g->ws, s));
   for (ConvDesc& d : g->d2) RGP_TRY(upload_desc(d, g->ws, s));
+  for (ConvDesc& d : g->d1_pack) RGP_TRY(upload_desc(d, g->ws, s));
+  for (ConvDesc& d : g->d2_pack) RGP_TRY(upload_desc(d, g->ws, s));
   auto up = [&](const std::vector<int>& t, size_t off) -> int {
     RGP_HIP(hipMemcpyAsync(g->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
     return RGP_OK;

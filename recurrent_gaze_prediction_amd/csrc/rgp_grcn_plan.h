@@ -11,7 +11,8 @@ struct rgp_grcn {
   int B = 0, T = 0, P = 0, S = 0, dtype = RGP_BF16, save = 0, F = 0;
   rgp::ConvDesc proj, proj_rows, xconv, gzr, gc, d3;
   rgp::ConvDesc d3t;   // the folded 7x7 conv as a row-Toeplitz GEMM: 16 output pixels of a row per GEMM row (d3: x = 48 only)
-  std::vector<rgp::ConvDesc> d1, d2;
+  std::vector<rgp::ConvDesc> d1, d2;            // transposed convolutions: one problem per row phase py, N = (px, channel)
+  std::vector<rgp::ConvDesc> d1_pack, d2_pack;  // their filter-packing aliases (one per (py, px): a tap table of its own)
   // read_buffer tables (host copies + offsets)
   std::vector<int> tab_pad9_P, tab_pad9_S, tab_pad27, tab_pad55, tab_lin49_3S, tab_lin49_S;
   size_t o_pad9_P = 0, o_pad9_S = 0, o_pad27 = 0, o_pad55 = 0, o_lin49_3S = 0, o_lin49_S = 0;
