@@ -2,7 +2,7 @@
 # Copy the summaries of scripts/r03_profiles.sh (gpurun_out/r03/) into profiles/ (tracked).  usage: collect_profiles.sh [round tag]
 R=${1:-r03}
 O=gpurun_out/$R
-st() { find $O/$1 -name "*kernel_stats.csv" | head -1; }
+st() { ls -t $(find $O/$1 -name "*kernel_stats.csv") | head -1; }   # the newest run (gpurun merges into an existing directory)
 cp $O/bench_e2e.json profiles/${R}_bench_e2e.json
 cp $O/bench_e2e_under_rocprof.json profiles/${R}_bench_e2e_under_rocprof.json
 cp "$(st stats_e2e)" profiles/${R}_e2e_kernel_stats.csv
