@@ -103,33 +103,51 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(const TS* __restr
 //   of the 49x49 map shifted by the SAME padding 3: source pixel (Y+3-u, X+3-v) - 3 ...)
 // Precisely: logit[y,x] = sum_{u,v,c} d2pad[y+u, x+v, c] Gp[u,v,c], d2pad = d2 with halo 3, so
 //   dd2[Y,X,c] = sum_{u,v} dz[Y+3-u, X+3-v] Gp[u,v,c]  with dz = 0 outside [0,49)^2.
-// One block per (frame, row Y): 49 pixels x 32 channels, Gp (1568 floats) in LDS.
+// One block per (frame, 7 rows Y0 .. Y0+6); a thread owns 7 consecutive pixels X of one row and 8 channels, so a filter
+// tap's 8 channels (two 16-byte LDS reads) serve 7 pixels and a row's 13 dz values serve its 7 taps: 18 LDS reads per 392
+// FMAs.  (Round 2's version -- a thread per (pixel, 8 channels), three LDS reads per 8 FMAs -- ran at the LDS bandwidth:
+// 61 us for 280 frames, 0.22 ms for 1024.)
 template <typename T>
 __global__ __launch_bounds__(256) void head_fold_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ gp,
                                                               T* __restrict__ dd2) {
-  __shared__ float s_g[49 * 32];
-  __shared__ float s_dz[7][56];
-  const int f = blockIdx.y, Y = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_g[49 * 32];
+  __shared__ float s_dz[13][56];                              // rows Y0-3 .. Y0+9, columns x = -3 .. 52 (zero outside the map)
+  const int f = blockIdx.y, Y0 = blockIdx.x * 7;
   for (int i = threadIdx.x; i < 49 * 32; i += 256) s_g[i] = gp[i];
-  for (int i = threadIdx.x; i < 7 * 56; i += 256) {
-    const int u = i / 56, xx = i % 56;            // row y = Y+3-u, column x = xx-3
-    const int y = Y + 3 - u, x = xx - 3;
-    s_dz[u][xx] = (y >= 0 && y < 49 && x >= 0 && x < 49) ? dz[((long long)f * 49 + y) * 49 + x] : 0.f;
+  for (int i = threadIdx.x; i < 13 * 56; i += 256) {
+    const int ry = i / 56, xx = i - ry * 56;
+    const int y = Y0 - 3 + ry, x = xx - 3;
+    s_dz[ry][xx] = (y >= 0 && y < 49 && x >= 0 && x < 49) ? dz[((long long)f * 49 + y) * 49 + x] : 0.f;
   }
   __syncthreads();
-  for (int it = threadIdx.x; it < 49 * 4; it += 256) {
-    const int X = it >> 2, cg = it & 3;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int u = 0; u < 7; ++u)
+  if (threadIdx.x >= 196) return;
+  const int cg = threadIdx.x & 3, xg = (threadIdx.x >> 2) % 7, yl = threadIdx.x / 28;
+  float acc[7][8];
 #pragma unroll
-      for (int v = 0; v < 7; ++v) {
-        const float d = s_dz[u][X + 3 - v + 3];
-        const float* g = s_g + (u * 7 + v) * 32 + cg * 8;
+  for (int xi = 0; xi < 7; ++xi)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += d * g[i];
+    for (int i = 0; i < 8; ++i) acc[xi][i] = 0.f;
+  for (int u = 0; u < 7; ++u) {
+    // source row Y + 3 - u = s_dz row yl + 6 - u; pixel X = 7 xg + xi reads columns X + 3 - v = s_dz column X + 6 - v
+    const float* drow = s_dz[yl + 6 - u] + 7 * xg;
+    float d[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) d[k] = drow[k];
+#pragma unroll
+    for (int v = 0; v < 7; ++v) {
+      const f32x4 g0 = *(const f32x4*)(s_g + (u * 7 + v) * 32 + cg * 8);
+      const f32x4 g1 = *(const f32x4*)(s_g + (u * 7 + v) * 32 + cg * 8 + 4);
+#pragma unroll
+      for (int xi = 0; xi < 7; ++xi) {
+        const float dv = d[xi + 6 - v];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[xi][i] += dv * g0[i]; acc[xi][4 + i] += dv * g1[i]; }
       }
-    store8<T>(dd2 + (((long long)f * 49 + Y) * 49 + X) * 32 + cg * 8, acc, 8);
+    }
   }
+#pragma unroll
+  for (int xi = 0; xi < 7; ++xi)
+    store8<T>(dd2 + (((long long)f * 49 + Y0 + yl) * 49 + 7 * xg + xi) * 32 + cg * 8, acc[xi], 8);
 }
 
 // ... and w.r.t. the folded filter: dGp[u,v,c] += sum_{f,y,x} dz[f,y,x] * d2pad[f, y+u, x+v, c].

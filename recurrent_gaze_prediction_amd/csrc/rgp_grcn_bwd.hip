@@ -155,7 +155,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_HIP(hipGetLastError());
   }
   head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
-  head_fold_dgrad_kernel<T><<<dim3(49, F), 256, 0, s>>>(Fp(b->dz), Fp(b->gp), Tp(b->dd2));
+  head_fold_dgrad_kernel<T><<<dim3(7, F), 256, 0, s>>>(Fp(b->dz), Fp(b->gp), Tp(b->dd2));
   RGP_HIP(hipGetLastError());
   // 3. deconv2: wgrad (dF2[a,b,o,c] = sum dd2[2i+a,2j+b,o] d1[i,j,c]) and dgrad
   {  // rows = the 23x23 positions of d1; X = dd2 at the stride-2 row origins (taps of b_d2), dY = the padded d1 image
