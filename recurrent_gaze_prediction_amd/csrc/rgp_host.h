@@ -293,10 +293,10 @@ IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
       if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024) return TILE_WIDE_512x128;
     }
   }
-  // (256 row tiles, or at least three 256x128 tiles per CU for its persistent walk; round 3: was M >= 65 536 alone, which
+  // (256 row tiles, or at least two 256x128 tiles per CU for its persistent walk; round 3: was M >= 65 536 alone, which
   // kept the head's hoisted W.x convolution and projection at 1024 frames -- M = 50 176 -- on the 128x128 tile)
   if (ksplit == 1 && G == 1 && tile_cfg == 2 && p.N % 128 == 0 && p.nk <= StaggerSmem::KOFF_MAX &&
-      (p.M >= 256 * 256 || (long long)((p.M + 255) / 256) * (p.N / 128) >= 768)) return TILE_STAGGER_256x128;
+      (p.M >= 256 * 256 || (long long)((p.M + 255) / 256) * (p.N / 128) >= 512)) return TILE_STAGGER_256x128;
   if (ksplit == 1 && p.N > 64 && tile_cfg == 1 && p.M >= 256 * 512) return TILE_LOOP_256x128;
   // one row tile and a wide output (the fc-GRU's recurrent GEMMs: M = B <= 64 rows, N = 1624 / 3248, K = 1624): even
   // 64x64 tiles give only 26 / 51 blocks, each bound by ONE CU's MFMA rate (40 us per launch, 32 launches per forward);
