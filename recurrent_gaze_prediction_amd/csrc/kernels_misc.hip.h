@@ -342,27 +342,53 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict
 // tf.nn.max_pool(ksize k, stride s, padding SAME) on NHWC (saliency_shallownet.py:117,134):
 // out = ceil(in/s), pad_before = max((out-1)*s + k - in, 0) / 2, padded cells ignored.
 // dst row stride ld_out elements per image (lets the flattened result be K-padded for the FC GEMM).
+// A thread owns 8 channels of one output (16-byte loads; C % 8 == 0).  amax (training plans, may be null): the place of
+// the FIRST maximum in the window's (row, column) scan order, a * k + b, one byte per output element -- what the gradient
+// routes through (rgp_shallownet.hip maxpool_same_bwd_kernel).
+__device__ __forceinline__ void mp_load8(const float* p, float* v) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void mp_load8(const bf16_t* p, float* v) {
+  const u32x4 a = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((bf16_t)(a[i] & 0xffffu)); v[2 * i + 1] = bf2f((bf16_t)(a[i] >> 16)); }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_same_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H,
                                                            int W, int C, int k, int s, int OH, int OW, int pt, int pl,
-                                                           long long ld_out) {
-  const long long total = (long long)N * OH * OW * C;
+                                                           long long ld_out, unsigned char* __restrict__ amax) {
+  const int CG = C / 8;
+  const long long total = (long long)N * OH * OW * CG;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const int ox = (int)((i / C) % OW);
-    const int oy = (int)((i / ((long long)C * OW)) % OH);
-    const long long n = i / ((long long)C * OW * OH);
-    float m = -INFINITY;
+    const int c = (int)(i % CG) * 8;
+    const int ox = (int)((i / CG) % OW);
+    const int oy = (int)((i / ((long long)CG * OW)) % OH);
+    const long long n = i / ((long long)CG * OW * OH);
+    float m[8];
+    unsigned code[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { m[q] = -INFINITY; code[q] = 0; }
     for (int a = 0; a < k; ++a) {
       const int y = oy * s - pt + a;
       if (y < 0 || y >= H) continue;
       for (int b = 0; b < k; ++b) {
         const int x = ox * s - pl + b;
         if (x < 0 || x >= W) continue;
-        m = fmaxf(m, Elem<T>::from(src[((n * H + y) * W + x) * C + c]));
+        float v[8];
+        mp_load8(src + ((n * H + y) * W + x) * C + c, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (v[q] > m[q]) { m[q] = v[q]; code[q] = (unsigned)(a * k + b); }
       }
     }
-    dst[n * ld_out + ((long long)oy * OW + ox) * C + c] = Elem<T>::to(m);
+    store8<T>(dst + n * ld_out + ((long long)oy * OW + ox) * C + c, m, 8);
+    if (amax) {
+      uint2 pk;
+      pk.x = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+      pk.y = code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24);
+      *(uint2*)(amax + ((n * OH + oy) * (long long)OW + ox) * C + c) = pk;
+    }
   }
 }
 

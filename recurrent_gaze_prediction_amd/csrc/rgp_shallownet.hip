@@ -28,6 +28,7 @@ struct rgp_shallownet {
   bool save = false;
   int last_n = 0;
   size_t amax1 = 0, mask1 = 0, mask2 = 0;         // conv1 pool arg-max [n][p1*p1][32]; maxout masks [n][2401]
+  size_t amax2 = 0, amax3 = 0;                    // pool2 / pool3 first-maximum places [n][p2*p2][64], [n][p3*p3][32]
   ConvDesc b_fc2, b_fc1, b_c3, b_c2;               // input-gradient GEMMs / "full" correlations with the rotated filters
   size_t dz2 = 0, dz1 = 0;                         // T [n+1][kFcN2]
   size_t dmo1 = 0, dpool3 = 0, dpool2 = 0, dpool1 = 0;   // fp32 [n][K2], [n][Kf], [n][p2*p2*64], [n][p1*p1*32]
@@ -77,12 +78,12 @@ int set_weights_impl(rgp_shallownet* g, const rgp_shallownet_weights* w, hipStre
 }
 
 template <typename T>
-int pool(const T* src, T* dst, int N, int H, int C, int k, int st, long long ld_out, hipStream_t s) {
+int pool(const T* src, T* dst, int N, int H, int C, int k, int st, long long ld_out, hipStream_t s, unsigned char* amax = nullptr) {
   const int OH = (H + st - 1) / st;
   const int pad = std::max((OH - 1) * st + k - H, 0) / 2;
-  const long long total = (long long)N * OH * OH * C;
+  const long long total = (long long)N * OH * OH * (C / 8);
   maxpool_same_kernel<T><<<(int)std::min<long long>((total + 255) / 256, 8192), 256, 0, s>>>(src, dst, N, H, H, C, k, st, OH, OH,
-                                                                                      pad, pad, ld_out);
+                                                                                      pad, pad, ld_out, amax);
   RGP_HIP(hipGetLastError());
   return RGP_OK;
 }
@@ -108,14 +109,16 @@ int forward_impl(rgp_shallownet* g, const float* frames, int n, float* sal, floa
     e.bias = g->b_conv2;
     RGP_TRY((launch_igemm<T, G32, 1, EpiStore<T, true, true>>(p, e, s)));
   }
-  RGP_TRY(pool<T>((const T*)(ws + g->act2), (T*)(ws + g->pool2), n, g->c2, 64, 3, 2, (long long)g->p2 * g->p2 * 64, s));
+  RGP_TRY(pool<T>((const T*)(ws + g->act2), (T*)(ws + g->pool2), n, g->c2, 64, 3, 2, (long long)g->p2 * g->p2 * 64, s,
+                  g->save ? (unsigned char*)(ws + g->amax2) : nullptr));
   {
     IgemmParams p = make_params(g->conv3, ws + g->pool2, ws, n);
     EpiParams e = make_epi(g->conv3, ws + g->act3, ws);
     e.bias = g->b_conv3;
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, true, true>>(p, e, s)));
   }
-  RGP_TRY(pool<T>((const T*)(ws + g->act3), (T*)(ws + g->pool3), n, g->c3, 32, 3, 2, g->Kf, s));
+  RGP_TRY(pool<T>((const T*)(ws + g->act3), (T*)(ws + g->pool3), n, g->c3, 32, 3, 2, g->Kf, s,
+                  g->save ? (unsigned char*)(ws + g->amax3) : nullptr));
   {
     IgemmParams p = make_params(g->fc1, ws + g->pool3, ws, n);
     EpiParams e = make_epi(g->fc1, ws + g->mo1, ws);
@@ -154,42 +157,45 @@ void conv_valid_desc(ConvDesc& d, int H_in, int k, int Cin, int Cout, int out_h,
 // maximum of its window; windows overlap, so each input position gathers from the (up to 4) windows that cover it.
 // x: the conv output after ReLU, dense [n][H][H][C]; dyp: fp32, image stride ld_img, element (oy*OH+ox)*C + c;
 // out: gradient w.r.t. the conv pre-activation in a halo-padded image [n][H+2h][H+2h][C] (h = halo).
+// A thread owns 8 channels of one input position; the forward pass recorded each window's first maximum (its place in
+// the scan order, kernels_misc.hip.h maxpool_same_kernel), so a window costs one 8-byte and one 32-byte load.  (Round 2's
+// version -- a thread per element that re-scanned every covering window, up to 36 two-byte loads each -- was 43 % of
+// config 1's training step: 1.16 ms per launch at 512 frames.)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_same_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dyp,
                                                                long long ld_img, T* __restrict__ out, int n, int H, int C, int k,
-                                                               int st, int OH, int pad, int halo) {
-  const long long total = (long long)n * H * H * C;
+                                                               int st, int OH, int pad, int halo, const unsigned char* __restrict__ amax) {
+  const int CG = C / 8;
+  const long long total = (long long)n * H * H * CG;
   const int Hp = H + 2 * halo;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const int xx = (int)((i / C) % H);
-    const int yy = (int)((i / ((long long)C * H)) % H);
-    const long long img = i / ((long long)C * H * H);
-    const T* xi = x + img * H * H * C;
-    const float v = Elem<T>::from(xi[((long long)yy * H + xx) * C + c]);
-    float acc = 0.f;
-    if (v > 0.f) {
+    const int c = (int)(i % CG) * 8;
+    const int xx = (int)((i / CG) % H);
+    const int yy = (int)((i / ((long long)CG * H)) % H);
+    const long long img = i / ((long long)CG * H * H);
+    float v[8], acc[8];
+    mp_load8(x + ((img * H + yy) * H + xx) * C + c, v);
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { acc[q] = 0.f; any |= v[q] > 0.f; }
+    if (any) {
       const int oy0 = max(0, (yy + pad - k + 1 + st - 1) / st), oy1 = min(OH - 1, (yy + pad) / st);
       const int ox0 = max(0, (xx + pad - k + 1 + st - 1) / st), ox1 = min(OH - 1, (xx + pad) / st);
       for (int oy = oy0; oy <= oy1; ++oy)
         for (int ox = ox0; ox <= ox1; ++ox) {
-          // first maximum of window (oy, ox) in (wy, wx) scan order
-          float best = -INFINITY;
-          int by = -1, bx = -1;
-          for (int wy = 0; wy < k; ++wy) {
-            const int y2 = oy * st - pad + wy;
-            if (y2 < 0 || y2 >= H) continue;
-            for (int wx = 0; wx < k; ++wx) {
-              const int x2 = ox * st - pad + wx;
-              if (x2 < 0 || x2 >= H) continue;
-              const float w = Elem<T>::from(xi[((long long)y2 * H + x2) * C + c]);
-              if (w > best) { best = w; by = y2; bx = x2; }
-            }
+          const unsigned own = (unsigned)((yy - (oy * st - pad)) * k + (xx - (ox * st - pad)));   // this position's place in the window
+          const long long w = ((img * OH + oy) * (long long)OH + ox) * C + c;
+          const uint2 code8 = *(const uint2*)(amax + w);
+          float d[8];
+          mp_load8(dyp + img * ld_img + ((long long)oy * OH + ox) * C + c, d);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const unsigned code = ((q < 4 ? code8.x : code8.y) >> (8 * (q & 3))) & 0xffu;
+            acc[q] += (code == own && v[q] > 0.f) ? d[q] : 0.f;
           }
-          if (by == yy && bx == xx) acc += dyp[img * ld_img + ((long long)oy * OH + ox) * C + c];
         }
     }
-    out[((img * Hp + yy + halo) * Hp + xx + halo) * C + c] = Elem<T>::to(acc);
+    store8<T>(out + ((img * Hp + yy + halo) * Hp + xx + halo) * C + c, acc, 8);
   }
 }
 
@@ -198,17 +204,27 @@ __global__ __launch_bounds__(256) void maxpool_same_bwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void unpool2x2_kernel(const float* __restrict__ dyp, const unsigned char* __restrict__ amax,
                                                         const T* __restrict__ pooled, T* __restrict__ dy, int n, int PH, int C) {
-  const long long total = (long long)n * PH * PH * C;
+  const int CG = C / 8;                                       // a thread owns 8 channels of a window: 16-byte loads / stores
+  const long long total = (long long)n * PH * PH * CG;
   const int H = 2 * PH;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const int xo = (int)((i / C) % PH);
-    const int yo = (int)((i / ((long long)C * PH)) % PH);
-    const long long img = i / ((long long)C * PH * PH);
-    const float g = Elem<T>::from(pooled[i]) > 0.f ? dyp[i] : 0.f;
-    const int code = amax[i];
-    for (int q = 0; q < 4; ++q)
-      dy[((img * H + 2 * yo + (q >> 1)) * H + 2 * xo + (q & 1)) * C + c] = Elem<T>::to(q == code ? g : 0.f);
+    const int c = (int)(i % CG) * 8;
+    const int xo = (int)((i / CG) % PH);
+    const int yo = (int)((i / ((long long)CG * PH)) % PH);
+    const long long img = i / ((long long)CG * PH * PH);
+    const long long e = ((img * PH + yo) * PH + xo) * C + c;
+    float pv[8], g[8];
+    mp_load8(pooled + e, pv);
+    mp_load8(dyp + e, g);
+    const uint2 code8 = *(const uint2*)(amax + e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = pv[k] > 0.f ? g[k] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (((k < 4 ? code8.x : code8.y) >> (8 * (k & 3))) & 0xffu) == (unsigned)q ? g[k] : 0.f;
+      store8<T>(dy + ((img * H + 2 * yo + (q >> 1)) * H + 2 * xo + (q & 1)) * C + c, v, 8);
+    }
   }
 }
 
@@ -227,8 +243,10 @@ __global__ __launch_bounds__(256) void conv_bias_grad_kernel(const T* __restrict
     const int yy = (int)((r / H) % H);
     const long long img = r / ((long long)H * H);
     const T* q = base + img * img_stride + (long long)yy * row_stride + (long long)xx * C + cg * 8;
+    float v[8];
+    mp_load8(q, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bsum[k] += Elem<T>::from(q[k]);
+    for (int k = 0; k < 8; ++k) bsum[k] += v[k];
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[rl * C + cg * 8 + k] = bsum[k];
@@ -275,6 +293,8 @@ bool bwd_plan(rgp_shallownet* g, Arena& a) {
   if (!ok) return false;
   for (ConvDesc* d : {&g->b_fc2, &g->b_fc1, &g->b_c3, &g->b_c2}) d->reserve(a, dtype);
   g->amax1 = a.take(n * g->p1 * g->p1 * 32);
+  g->amax2 = a.take(n * g->p2 * g->p2 * 64);
+  g->amax3 = a.take(n * g->p3 * g->p3 * 32);
   g->mask1 = a.take(n * 2401);
   g->mask2 = a.take(n * 2401);
   g->dz2 = a.take((n + 1) * kFcN2 * es + 1024);
@@ -312,7 +332,7 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   // ---- fully connected read-out (saliency_shallownet.py:139-185)
   maxout_bwd_kernel<T><<<nblk((long long)n * 2401), 256, 0, s>>>(d_sal, 2401, nullptr, 1.0f, (const unsigned char*)(ws + g->mask2),
                                                                  Tp(g->dz2), (long long)n * 2401);
-  fc_bias_grad_kernel<T><<<(4802 + 255) / 256, 256, 0, s>>>(Tp(g->dz2), n, (float*)gr->fc2_b);
+  fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, s>>>(Tp(g->dz2), n, (float*)gr->fc2_b);
   RGP_HIP(hipGetLastError());
   RGP_TRY(fc_wgrad(ws + g->mo1, g->K2, g->fc2, g->dz2, (float*)gr->fc2_w, 2401));
   {
@@ -322,7 +342,7 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   }
   maxout_bwd_kernel<T><<<nblk((long long)n * 2401), 256, 0, s>>>(Fp(g->dmo1), g->K2, nullptr, 1.0f, (const unsigned char*)(ws + g->mask1),
                                                                  Tp(g->dz1), (long long)n * 2401);
-  fc_bias_grad_kernel<T><<<(4802 + 255) / 256, 256, 0, s>>>(Tp(g->dz1), n, (float*)gr->fc1_b);
+  fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, s>>>(Tp(g->dz1), n, (float*)gr->fc1_b);
   RGP_HIP(hipGetLastError());
   RGP_TRY(fc_wgrad(ws + g->pool3, g->Kf, g->fc1, g->dz1, (float*)gr->fc1_w, g->nflat));
   {
@@ -345,10 +365,10 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   };
   {
     const int H = g->c3, OH = g->p3, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
-    maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 32), 256, 0, s>>>(Tp(g->act3), Fp(g->dpool3), g->Kf, Tp(g->dy3), n, H, 32, 3, 2,
-                                                                              OH, pad, 2);
+    maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 4), 256, 0, s>>>(Tp(g->act3), Fp(g->dpool3), g->Kf, Tp(g->dy3), n, H, 32, 3, 2,
+                                                                              OH, pad, 2, (const unsigned char*)(ws + g->amax3));
     RGP_HIP(hipMemsetAsync((void*)gr->conv3_b, 0, 32 * 4, s));
-    conv_bias_grad_kernel<T><<<nblk((long long)n * H * H * 2), 256, 0, s>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, (long long)Wp * Wp * 32, H, Wp * 32,
+    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 2), 1024), 256, 0, s>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, (long long)Wp * Wp * 32, H, Wp * 32,
                                                                            32, (long long)n * H * H, (float*)gr->conv3_b);
     RGP_HIP(hipGetLastError());
     RGP_TRY(conv_wgrad(ws + g->pool2, g->p2, 64, g->conv3, g->dy3, H, 32, (float*)gr->conv3_w, 1));
@@ -359,10 +379,10 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   // ---- conv2 (3x3 VALID 32 -> 64) behind pool2
   {
     const int H = g->c2, OH = g->p2, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
-    maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 64), 256, 0, s>>>(Tp(g->act2), Fp(g->dpool2), (long long)OH * OH * 64, Tp(g->dy2),
-                                                                              n, H, 64, 3, 2, OH, pad, 2);
+    maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 8), 256, 0, s>>>(Tp(g->act2), Fp(g->dpool2), (long long)OH * OH * 64, Tp(g->dy2),
+                                                                              n, H, 64, 3, 2, OH, pad, 2, (const unsigned char*)(ws + g->amax2));
     RGP_HIP(hipMemsetAsync((void*)gr->conv2_b, 0, 64 * 4, s));
-    conv_bias_grad_kernel<T><<<nblk((long long)n * H * H * 4), 256, 0, s>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, (long long)Wp * Wp * 64, H, Wp * 64,
+    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 4), 1024), 256, 0, s>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, (long long)Wp * Wp * 64, H, Wp * 64,
                                                                            64, (long long)n * H * H, (float*)gr->conv2_b);
     RGP_HIP(hipGetLastError());
     RGP_TRY(conv_wgrad(ws + g->pool1, g->p1, 32, g->conv2, g->dy2, H, 64, (float*)gr->conv2_w, G32));
@@ -374,10 +394,10 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   {
     const int H = g->c1, IH = g->IH;
     T* dy1 = Tp(g->dy1) + 128;
-    unpool2x2_kernel<T><<<nblk((long long)n * g->p1 * g->p1 * 32), 256, 0, s>>>(Fp(g->dpool1), (const unsigned char*)(ws + g->amax1),
+    unpool2x2_kernel<T><<<nblk((long long)n * g->p1 * g->p1 * 4), 256, 0, s>>>(Fp(g->dpool1), (const unsigned char*)(ws + g->amax1),
                                                                                Tp(g->pool1), dy1, n, g->p1, 32);
     RGP_HIP(hipMemsetAsync((void*)gr->conv1_b, 0, 32 * 4, s));
-    conv_bias_grad_kernel<T><<<nblk((long long)n * H * H * 2), 256, 0, s>>>(dy1, (long long)H * H * 32, H, H * 32, 32, (long long)n * H * H,
+    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 2), 1024), 256, 0, s>>>(dy1, (long long)H * H * 32, H, H * 32, 32, (long long)n * H * H,
                                                                            (float*)gr->conv1_b);
     RGP_HIP(hipGetLastError());
     RGP_HIP(hipMemsetAsync(Fp(g->dw1), 0, (size_t)g->conv1.nk * BKE * 32 * 4, s));

@@ -25,14 +25,24 @@ __global__ __launch_bounds__(256) void maxout_bwd_kernel(const float* __restrict
   }
 }
 
-// bias gradient of an FC: db[col] = sum_f dz[f+1][col]
+// bias gradient of an FC: db[col] = sum_f dz[f+1][col].  Block = 32 columns x 8 row lanes (a thread per column looping
+// over all F rows -- 19 blocks, F dependent loads each -- took 0.19 ms at 512 frames); launch with (4802 + 31) / 32 blocks.
 template <typename T>
-__global__ void fc_bias_grad_kernel(const T* __restrict__ dz, int F, float* __restrict__ db) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= 4802) return;
+__global__ __launch_bounds__(256) void fc_bias_grad_kernel(const T* __restrict__ dz, int F, float* __restrict__ db) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
   float a = 0.f;
-  for (int f = 0; f < F; ++f) a += Elem<T>::from(dz[(long long)(f + 1) * kFcN2 + col]);
-  db[col] = a;
+  if (col < 4802)
+    for (int f = rl; f < F; f += 8) a += Elem<T>::from(dz[(long long)(f + 1) * kFcN2 + col]);
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && col < 4802) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    db[col] = t;
+  }
 }
 
 }  // namespace rgp
