@@ -312,11 +312,26 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
 
 // ---- optimizer (base.py:262-308; TF semantics) ------------------------------
 // partial[b] = sum of squares of block b's grid-stride share (deterministic two-stage norm)
+// (16-byte loads, four in flight per thread: the scalar loop it replaces read 123 MB -- the 30.7 M gradients of the
+// end-to-end model -- at 0.5 TB/s)
 static __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long n,
                                                              float* __restrict__ partial) {
   __shared__ float sh[4];
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
   float a = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) a += g[i] * g[i];
+  // leading elements up to a 16-byte boundary, whole 16-byte groups, tail
+  const long long head = min(n, (long long)((16 - ((size_t)g & 15)) & 15) / 4);
+  const long long n4 = (n - head) >> 2;
+  const f32x4* g4 = (const f32x4*)(g + head);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+  for (long long i = tid; i < n4; i += stride) {
+    const f32x4 v = g4[i];
+    a0 += v[0] * v[0]; a1 += v[1] * v[1]; a2 += v[2] * v[2]; a3 += v[3] * v[3];
+  }
+  a = (a0 + a1) + (a2 + a3);
+  for (long long i = tid; i < head; i += stride) a += g[i] * g[i];
+  for (long long i = head + 4 * n4 + tid; i < n; i += stride) a += g[i] * g[i];
   a = block_reduce(a, sh, false);
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
 }

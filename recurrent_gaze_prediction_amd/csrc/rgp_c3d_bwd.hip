@@ -101,9 +101,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ buf, 
   for (long long r = (long long)blockIdx.x * RL + rl; r < rows_total; r += (long long)gridDim.x * RL) {
     const long long img = r / Mw;
     const int ml = (int)(r - img * Mw);
-    const T* p = buf + img * img_stride + tab[ml] + cg * 8;
+    float v[8];
+    mp_load8(buf + img * img_stride + tab[ml] + cg * 8, v);        // (16-byte load: kernels_misc.hip.h)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bsum[k] += Elem<T>::from(p[k]);
+    for (int k = 0; k < 8; ++k) bsum[k] += v[k];
   }
   block_colsum(bsum, cg, rl, RL, C, db);
 }
@@ -161,7 +162,8 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     const int Mw = l.D * l.H * l.H;
     if (!pooled(i)) {  // bias gradient (pooled layers: done by unpool below)
       const long long rows = (long long)n * Mw;
-      colsum_kernel<T><<<blocks_for(rows, 256 / (l.cout / 8) * 16), 256, 0, s>>>(
+      colsum_kernel<T><<<std::min(blocks_for(rows, 256 / (l.cout / 8) * 16), 1024), 256, 0, s>>>(      // (every block ends with C atomics)
+          
           (const T*)(ws + b.dypre_off), (const int*)(ws + b.y_tab_off), b.dypre_stride, Mw, l.cout, rows, grads + b.grad_b);
       RGP_HIP(hipGetLastError());
     }
