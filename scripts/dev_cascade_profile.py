@@ -1,0 +1,19 @@
+"""Dev: cascade (config 5's head) forward + backward loop for rocprofv3."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recurrent_gaze_prediction_amd import synthetic as syn
+from recurrent_gaze_prediction_amd.engine import CascadeEngine
+
+dev = torch.device('cuda:0')
+B, T = 16, 35
+eng = CascadeEngine(B, T, 98, dtype='bf16', device=dev, save_for_backward=True)
+eng.set_weights(syn.cascade_params(0))
+frames = torch.rand(B, T, 98, 98, 3, device=dev)
+c3d = torch.tensor(syn.c3d_features(1, B, T), device=dev)
+gt = torch.rand(B, T, 49, 49, device=dev)
+for _ in range(10):
+    eng.backward(eng.forward(frames, c3d), gt, want_d_rows=True)
+torch.cuda.synchronize()
+print('done')
