@@ -15,6 +15,11 @@ Fixtures hold seeds + expected outputs only: inputs and weights are regenerated 
   shapes (the only case exercised: 49x49 maps), and ``np.bool`` / ``np.int`` aliases
   removed in numpy >= 1.24.  AUC_shuffled is not generated: the reference's
   implementation raises under Python 3 (evaluation_metrics.py:200-201).
+* c3d_wire_ref.npz: the C3D feature files as the REFERENCE reads and writes them: its own ``read_binary_blob`` and
+  ``process_c3d_features`` (C3D/.../hollywood_feature_extraction/extract_C3D_features.py:13-76, 763-798), imported with
+  two in-memory shims for modules absent here that those two functions do not touch (``cv2``, ``h5py``), run on blob
+  files this script writes byte by byte (header of five int32, then float32 data).  The fixture holds the blob bytes,
+  the array the reference decodes from them and the ``.c3d`` pickle it writes.
 """
 import importlib.util
 import os
@@ -206,7 +211,53 @@ def frontend_case(name, seed):
     print(name, 'checksum', float(np.abs(v.astype(np.float64)).sum()))
 
 
+REFERENCE_EXTRACT = ('/root/reference/C3D/C3D-v1.0/examples/c3d_feature_extraction/hollywood_feature_extraction/'
+                     'extract_C3D_features.py')
+
+
+def c3d_wire_case(name, seed=161, n_clips=2):
+    import shutil
+    import tempfile
+    for missing in ('cv2', 'h5py'):                          # imported at the top of the script, unused by the two functions
+        if missing not in sys.modules:
+            sys.modules[missing] = types.ModuleType(missing)
+    spec = importlib.util.spec_from_file_location('reference_extract_c3d', REFERENCE_EXTRACT)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rs = np.random.RandomState(seed)
+    tmp = tempfile.mkdtemp()
+    try:
+        feat_dir = os.path.join(tmp, 'videoA')
+        os.makedirs(feat_dir)
+        blobs = []
+        for k in range(n_clips):
+            # sparse (the fixture compresses to a few KB), every value exactly representable; conv5b is post-ReLU anyway
+            data = np.zeros((1, 512, 2, 7, 7), '<f4')
+            idx = rs.choice(data.size, 400, replace=False)
+            data.reshape(-1)[idx] = rs.randint(1, 200, size=400) / 8.0
+            raw = np.array([1, 512, 2, 7, 7], dtype='<i4').tobytes() + data.tobytes()
+            with open(os.path.join(feat_dir, '%06d.conv5b' % (16 * k + 1)), 'wb') as f:
+                f.write(raw)
+            blobs.append(np.frombuffer(raw, dtype=np.uint8))
+        size, blob, status = ref.read_binary_blob(os.path.join(feat_dir, '000001.conv5b'))
+        assert status == 1 and list(size) == [1, 512, 2, 7, 7]
+        ref.process_c3d_features(feat_dir, 'conv5b')
+        with open(os.path.join(tmp, 'videoA.c3d'), 'rb') as f:
+            c3d_bytes = f.read()
+        import pickle
+        stacked = pickle.loads(c3d_bytes, encoding='latin1')
+        np.savez_compressed(os.path.join(HERE, name), blob_bytes=np.stack(blobs), ref_size=np.array(list(size)),
+                            ref_blob0=np.asarray(blob.data, np.float32), c3d_pickle=np.frombuffer(c3d_bytes, dtype=np.uint8),
+                            c3d_array=np.asarray(stacked, np.float32))
+        print(name, 'blob0', np.asarray(blob.data).shape, '.c3d', np.asarray(stacked).shape, len(c3d_bytes), 'bytes')
+    finally:
+        shutil.rmtree(tmp)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'wire':        # reference-pinned C3D feature-file fixture (round 3)
+        c3d_wire_case('c3d_wire_ref.npz')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'new':         # fixtures added after the first set
         cascade_case('cascade_small.npz', 1, 2, 131)
         fcgru_case('fcgru_small.npz', 2, 3, 7, 141)
