@@ -19,7 +19,8 @@ Fixtures hold seeds + expected outputs only: inputs and weights are regenerated 
   ``process_c3d_features`` (C3D/.../hollywood_feature_extraction/extract_C3D_features.py:13-76, 763-798), imported with
   two in-memory shims for modules absent here that those two functions do not touch (``cv2``, ``h5py``), run on blob
   files this script writes byte by byte (header of five int32, then float32 data).  The fixture holds the blob bytes,
-  the array the reference decodes from them and the ``.c3d`` pickle it writes.
+  the array the reference decodes from them, the ``.c3d`` pickle it writes, and the ``input.txt`` / ``output_prefix.txt``
+  its ``create_src_and_output_file`` (:653-686) writes for a given clip and window schedule.
 """
 import importlib.util
 import os
@@ -246,9 +247,17 @@ def c3d_wire_case(name, seed=161, n_clips=2):
             c3d_bytes = f.read()
         import pickle
         stacked = pickle.loads(c3d_bytes, encoding='latin1')
+        # the input / output-prefix lists the Caffe extractor is driven by (extract_C3D_features.py:653-686)
+        lists = os.path.join(tmp, 'lists')
+        os.makedirs(lists)
+        starts = [0, 16, 32, 48]
+        ref.create_src_and_output_file('/videos/actioncliptest00012.avi', starts, lists, '/data/frames', '/data/feat')
+        input_txt = open(os.path.join(lists, 'input.txt')).read()
+        prefix_txt = open(os.path.join(lists, 'output_prefix.txt')).read()
         np.savez_compressed(os.path.join(HERE, name), blob_bytes=np.stack(blobs), ref_size=np.array(list(size)),
                             ref_blob0=np.asarray(blob.data, np.float32), c3d_pickle=np.frombuffer(c3d_bytes, dtype=np.uint8),
-                            c3d_array=np.asarray(stacked, np.float32))
+                            c3d_array=np.asarray(stacked, np.float32), list_starts=np.array(starts),
+                            input_txt=np.array(input_txt), output_prefix_txt=np.array(prefix_txt))
         print(name, 'blob0', np.asarray(blob.data).shape, '.c3d', np.asarray(stacked).shape, len(c3d_bytes), 'bytes')
     finally:
         shutil.rmtree(tmp)
