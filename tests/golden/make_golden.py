@@ -15,6 +15,8 @@ Fixtures hold seeds + expected outputs only: inputs and weights are regenerated 
   shapes (the only case exercised: 49x49 maps), and ``np.bool`` / ``np.int`` aliases
   removed in numpy >= 1.24.  AUC_shuffled is not generated: the reference's
   implementation raises under Python 3 (evaluation_metrics.py:200-201).
+* model_util_ref.npz: outputs of the REFERENCE's numpy map normalisers (models/model_util.py:20-58; ``tensorflow``, which the
+  file imports and these functions never touch, replaced by an empty module).
 * c3d_wire_ref.npz: the C3D feature files as the REFERENCE reads and writes them: its own ``read_binary_blob`` and
   ``process_c3d_features`` (C3D/.../hollywood_feature_extraction/extract_C3D_features.py:13-76, 763-798), imported with
   two in-memory shims for modules absent here that those two functions do not touch (``cv2``, ``h5py``), run on blob
@@ -263,7 +265,33 @@ def c3d_wire_case(name, seed=161, n_clips=2):
         shutil.rmtree(tmp)
 
 
+REFERENCE_MODEL_UTIL = '/root/reference/models/model_util.py'
+
+
+def model_util_case(name, seed=171):
+    """The reference's numpy map normalisers (models/model_util.py:20-58), imported with an EMPTY stand-in for
+    `tensorflow` (absent here; the file imports it at the top, these two functions never touch it)."""
+    if 'tensorflow' not in sys.modules:
+        sys.modules['tensorflow'] = types.ModuleType('tensorflow')
+    spec = importlib.util.spec_from_file_location('reference_model_util', REFERENCE_MODEL_UTIL)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rs = np.random.RandomState(seed)
+    maps3 = (rs.rand(4, 9, 9) * 3 + 0.1).astype(np.float32)
+    maps3[2] = 0.25                                            # a constant map: max after the shift is 0
+    maps4 = (rs.rand(2, 3, 7, 7) + 0.05).astype(np.float32)
+    maps4b = (rs.rand(3, 6, 6, 1) * 5).astype(np.float32)      # [B, H, W, 1] for normalize_map
+    np.savez_compressed(os.path.join(HERE, name), maps3=maps3, maps4=maps4, maps4b=maps4b,
+                        norm3=ref.normalize_map(maps3), norm4b=ref.normalize_map(maps4b),
+                        prob3=ref.normalize_probability_map(maps3), prob4=ref.normalize_probability_map(maps4),
+                        prob3_f64=ref.normalize_probability_map(maps3.astype(np.float64)))
+    print(name, 'ok')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'util':        # reference-pinned numpy normalisers (round 3)
+        model_util_case('model_util_ref.npz')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'wire':        # reference-pinned C3D feature-file fixture (round 3)
         c3d_wire_case('c3d_wire_ref.npz')
         sys.exit(0)
