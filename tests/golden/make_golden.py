@@ -15,6 +15,8 @@ Fixtures hold seeds + expected outputs only: inputs and weights are regenerated 
   shapes (the only case exercised: 49x49 maps), and ``np.bool`` / ``np.int`` aliases
   removed in numpy >= 1.24.  AUC_shuffled is not generated: the reference's
   implementation raises under Python 3 (evaluation_metrics.py:200-201).
+* c3d_arch_ref.json: the layer table parsed from the prototxt the REFERENCE's generate_feature_prototxt writes
+  (extract_C3D_features.py:183-650; same import as c3d_wire_ref.npz).
 * model_util_ref.npz: outputs of the REFERENCE's numpy map normalisers (models/model_util.py:20-58; ``tensorflow``, which the
   file imports and these functions never touch, replaced by an empty module).
 * c3d_wire_ref.npz: the C3D feature files as the REFERENCE reads and writes them: its own ``read_binary_blob`` and
@@ -40,6 +42,8 @@ from oracle import grcn, torch_ref  # noqa: E402
 from recurrent_gaze_prediction_amd import synthetic as syn  # noqa: E402
 
 REFERENCE_METRICS = '/root/reference/evaluation_metrics.py'
+REFERENCE_EXTRACT = ('/root/reference/C3D/C3D-v1.0/examples/c3d_feature_extraction/hollywood_feature_extraction/'
+                     'extract_C3D_features.py')
 
 
 def grcn_case(name, B, T, P, S, seed, use_numpy):
@@ -214,10 +218,6 @@ def frontend_case(name, seed):
     print(name, 'checksum', float(np.abs(v.astype(np.float64)).sum()))
 
 
-REFERENCE_EXTRACT = ('/root/reference/C3D/C3D-v1.0/examples/c3d_feature_extraction/hollywood_feature_extraction/'
-                     'extract_C3D_features.py')
-
-
 def c3d_wire_case(name, seed=161, n_clips=2):
     import shutil
     import tempfile
@@ -268,6 +268,45 @@ def c3d_wire_case(name, seed=161, n_clips=2):
 REFERENCE_MODEL_UTIL = '/root/reference/models/model_util.py'
 
 
+def c3d_arch_case(name):
+    """The network the reference's extractor declares: its generate_feature_prototxt (extract_C3D_features.py:183-650) is run
+    here (same import as c3d_wire_case) and the text it writes is PARSED into a table -- layer order, types, filter counts,
+    kernel / pad / stride extents and the VIDEO_DATA geometry; the fixture holds the table, not the text."""
+    import json
+    import re
+    import tempfile
+    for missing in ('cv2', 'h5py'):
+        if missing not in sys.modules:
+            sys.modules[missing] = types.ModuleType(missing)
+    spec = importlib.util.spec_from_file_location('reference_extract_c3d', REFERENCE_EXTRACT)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    with tempfile.TemporaryDirectory() as tmp:
+        mean = os.path.join(tmp, 'mean.binaryproto')
+        open(mean, 'wb').close()
+        out = os.path.join(tmp, 'net.prototxt')
+        ref.generate_feature_prototxt(out, os.path.join(tmp, 'input.txt'), mean)
+        text = open(out).read()
+    text = re.sub(r'#.*', '', text)
+    layers = []
+    for body in re.findall(r'layers\s*\{(.*?)\n\}', text, flags=re.S):
+        get = lambda key, cast=str: [cast(v.strip('"')) for v in re.findall(r'\b%s:\s*("[^"]*"|\S+)' % key, body)]
+        entry = {'name': get('name')[0], 'type': get('type')[0], 'bottom': get('bottom'), 'top': get('top')}
+        for key in ('num_output', 'kernel_size', 'kernel_depth', 'pad', 'temporal_pad', 'stride', 'temporal_stride', 'crop_size',
+                    'new_height', 'new_width', 'new_length', 'batch_size'):
+            v = get(key, int)
+            if v:
+                entry[key] = v[0]
+        for key in ('pool', 'mirror', 'use_image', 'shuffle'):
+            v = get(key)
+            if v:
+                entry[key] = v[0]
+        layers.append(entry)
+    with open(os.path.join(HERE, name), 'w') as f:
+        json.dump({'net_name': re.findall(r'^name:\s*"([^"]*)"', text, flags=re.M)[0], 'layers': layers}, f, indent=1)
+    print(name, len(layers), 'layers:', ' '.join(l['name'] for l in layers))
+
+
 def model_util_case(name, seed=171):
     """The reference's numpy map normalisers (models/model_util.py:20-58), imported with an EMPTY stand-in for
     `tensorflow` (absent here; the file imports it at the top, these two functions never touch it)."""
@@ -289,6 +328,9 @@ def model_util_case(name, seed=171):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'arch':        # the C3D network as the reference's prototxt generator declares it
+        c3d_arch_case('c3d_arch_ref.json')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'util':        # reference-pinned numpy normalisers (round 3)
         model_util_case('model_util_ref.npz')
         sys.exit(0)
