@@ -12,6 +12,7 @@
 
 #include "train_kernels.hip.h"
 #include "wgrad_launch.h"
+#include "shallow_conv1.hip.h"
 
 using namespace rgp;
 
@@ -96,7 +97,13 @@ int forward_impl(rgp_shallownet* g, const float* frames, int n, float* sal, floa
   g->last_n = n;
   frame_prep_kernel<T><<<(int)std::min<long long>((npix + 255) / 256, 8192), 256, 0, s>>>(frames, (T*)(ws + g->frames4), npix);
   RGP_HIP(hipGetLastError());
-  {
+  if (sizeof(T) == 2 && shallow_conv1_covers(g->IH)) {      // bf16, 112 / 98 pixel frames: the frame kernel (shallow_conv1.hip.h)
+    ShallowConv1Params q;
+    q.frames4 = (const bf16_t*)(ws + g->frames4); q.wp = (const bf16_t*)(ws + g->conv1.w_off); q.bias = g->b_conv1;
+    q.pool1 = (bf16_t*)(ws + g->pool1); q.amax = g->save ? (unsigned char*)(ws + g->amax1) : nullptr;
+    q.n = n; q.ldw = g->conv1.K;
+    RGP_TRY(run_shallow_conv1(g->IH, q, s));
+  } else {
     IgemmParams p = make_params(g->conv1, ws + g->frames4, ws, n);
     EpiParams e = make_epi(g->conv1, ws + g->pool1, ws);
     e.bias = g->b_conv1;
