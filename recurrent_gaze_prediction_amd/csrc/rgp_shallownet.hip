@@ -97,7 +97,9 @@ int forward_impl(rgp_shallownet* g, const float* frames, int n, float* sal, floa
   g->last_n = n;
   frame_prep_kernel<T><<<(int)std::min<long long>((npix + 255) / 256, 8192), 256, 0, s>>>(frames, (T*)(ws + g->frames4), npix);
   RGP_HIP(hipGetLastError());
-  if (sizeof(T) == 2 && shallow_conv1_covers(g->IH)) {      // bf16, 112 / 98 pixel frames: the frame kernel (shallow_conv1.hip.h)
+  // bf16, 112 / 98 pixel frames, enough frames to give the CUs a workgroup each: the frame kernel (shallow_conv1.hip.h);
+  // a handful of frames (config 1's own batch of 2) spreads better as tiles of the general kernel (0.11 vs 0.14 ms)
+  if (sizeof(T) == 2 && shallow_conv1_covers(g->IH) && n >= 48) {
     ShallowConv1Params q;
     q.frames4 = (const bf16_t*)(ws + g->frames4); q.wp = (const bf16_t*)(ws + g->conv1.w_off); q.bias = g->b_conv1;
     q.pool1 = (bf16_t*)(ws + g->pool1); q.amax = g->save ? (unsigned char*)(ws + g->amax1) : nullptr;
