@@ -88,6 +88,37 @@ def test_shallownet_backward_matches_autograd(gpu, dtype, hw):
     assert not bad, bad
 
 
+@pytest.mark.parametrize('hw', [98, 112])
+def test_conv1_frame_kernel_against_the_general_tile_and_the_oracle(gpu, hw):
+    """From 48 frames up conv1 runs on shallow_conv1_bf16_kernel (a workgroup per frame); below, on the general
+    implicit-GEMM tile.  The same two frames through both: equal maps up to bf16 rounding, both inside the oracle
+    tolerance; and the arg-max codes the frame kernel records route the same gradient (all ten variables)."""
+    from recurrent_gaze_prediction_amd.engine import ShallowNetEngine
+    p = syn.shallownet_params(161, hw)
+    p = dict(p, conv1_b=np.linspace(-0.1, 0.1, 32).astype(np.float32))
+    rs = np.random.RandomState(162)
+    frames = rs.rand(48, hw, hw, 3).astype(np.float32)
+    g = np.zeros((48, 49, 49), np.float32)
+    g[:2] = rs.randn(2, 49, 49)
+    big = ShallowNetEngine(48, hw, dtype='bf16', device=gpu, save_for_backward=True)
+    small = ShallowNetEngine(4, hw, dtype='bf16', device=gpu, save_for_backward=True)
+    big.set_weights(p)
+    small.set_weights(p)
+    sal_big, _ = big.forward(torch.tensor(frames, device=gpu))
+    sal_small, _ = small.forward(torch.tensor(frames[:2], device=gpu))
+    ref = torch_ref.shallownet_forward(torch.tensor(frames[:2], dtype=torch.float64),
+                                       {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}).numpy()
+    assert rel_err(sal_big[:2].cpu().numpy(), ref) < TOL['bf16'] and rel_err(sal_small.cpu().numpy(), ref) < TOL['bf16']
+    assert rel_err(sal_big[:2].cpu().numpy(), sal_small.cpu().numpy()) < 1e-2
+    assert float((sal_big[2:] > 0).float().mean()) > 0.2           # the other 46 frames are not degenerate either
+    gb = big.backward(torch.tensor(g, device=gpu))
+    gs = small.backward(torch.tensor(g[:2], device=gpu))
+    for k in p:
+        a, b = gb[k].double().flatten(), gs[k].double().flatten()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1) < 2e-2, (k, cos)
+
+
 def test_framewise_training_through_the_model_api(gpu, tmp_path):
     """FramewiseShallowNet.single_step(train_mode=True): l2 loss on 49x49 maps, all ten variables move."""
     from recurrent_gaze_prediction_amd.models.base import Session
