@@ -13,8 +13,8 @@ Fixtures hold seeds + expected outputs only: inputs and weights are regenerated 
   (/root/reference/evaluation_metrics.py), imported here with three in-memory shims
   (SURVEY.md 8c): a ``skimage.transform.resize`` stand-in that is the identity at equal
   shapes (the only case exercised: 49x49 maps), and ``np.bool`` / ``np.int`` aliases
-  removed in numpy >= 1.24.  AUC_shuffled is not generated: the reference's
-  implementation raises under Python 3 (evaluation_metrics.py:200-201).
+  removed in numpy >= 1.24; and, for AUC_shuffled (evaluation_metrics.py:167-204), a module-level ``map`` that
+  returns a list as Python 2's did (``:200-201`` hands the result of ``map`` to ``np.transpose``).
 * c3d_arch_ref.json: the layer table parsed from the prototxt the REFERENCE's generate_feature_prototxt writes
   (extract_C3D_features.py:183-650; same import as c3d_wire_ref.npz).
 * model_util_ref.npz: outputs of the REFERENCE's numpy map normalisers (models/model_util.py:20-58; ``tensorflow``, which the
@@ -127,6 +127,8 @@ def load_reference_metrics():
         np.int = int
     spec = importlib.util.spec_from_file_location('reference_evaluation_metrics', REFERENCE_METRICS)
     mod = importlib.util.module_from_spec(spec)
+    import builtins
+    mod.map = lambda f, *a: list(builtins.map(f, *a))      # Python-2 ``map``: a list (AUC_shuffled, :200-201)
     spec.loader.exec_module(mod)
     return mod
 
@@ -150,7 +152,17 @@ def metrics_case(name, seed=40, n=12):
         np.random.seed(2000 + i)
         borji.append(ref.saliency_score_single('AUC_Borji', pred[i], gt[i], fix[i]))
     out.update(sim=np.array(sims), cc=np.array(ccs), AUC_Judd=np.array(judd), AUC_Borji=np.array(borji))
-    for metric in ('sim', 'cc', 'AUC_Borji'):
+    # AUC_shuffled: negatives from the union of the OTHER frames' fixations (what saliency_score builds, :283-287)
+    shuf = []
+    for i in range(n):
+        other = np.zeros(fix[0].shape)
+        for j in range(n):
+            if j != i:
+                other += (fix[j] > 0).astype(int)
+        np.random.seed(4000 + i)
+        shuf.append(ref.saliency_score_single('AUC_shuffled', pred[i], gt[i], fix[i], other))
+    out['AUC_shuffled'] = np.array(shuf)
+    for metric in ('sim', 'cc', 'AUC_Borji', 'AUC_shuffled'):
         np.random.seed(3000)
         out['score_' + metric] = np.float64(ref.saliency_score(metric, list(pred), list(gt), list(fix)))
     np.savez_compressed(os.path.join(HERE, name), **out)
@@ -336,6 +348,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'wire':        # reference-pinned C3D feature-file fixture (round 3)
         c3d_wire_case('c3d_wire_ref.npz')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':     # reference-pinned metric scores (round 4: + AUC_shuffled)
+        metrics_case('metrics_ref.npz')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'new':         # fixtures added after the first set
         cascade_case('cascade_small.npz', 1, 2, 131)
