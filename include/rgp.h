@@ -76,7 +76,8 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
 #define RGP_GRCN_PER_STEP 2
 /* The persistent ConvGRU kernels (one launch for all T steps, forward and BPTT) need all their workgroups resident
  * together: keep ONE of them in flight per device.  Launches issued through this library from one process are
- * serialised against each other automatically (any stream, any plan); a launch that nevertheless loses a group member
+ * serialised against each other automatically (any stream, any plan, any host thread: the wait for the previous
+ * launch, the launch and its record are one critical section); a launch that nevertheless loses a group member
  * -- another process running the same kernels on the device -- gives up after about a second, NaN-poisons everything
  * computed from it (logits, maps, states, gradients) and raises the plan's error state: the next call on the plan
  * returns RGP_ETIMEOUT, and so does rgp_grcn_status, which first waits for `stream`.  The state is cleared by being

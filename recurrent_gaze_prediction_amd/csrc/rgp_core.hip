@@ -52,26 +52,30 @@ bool stream_capturing(hipStream_t s) {
 }
 }  // namespace
 
-int persistent_guard_begin(hipStream_t s) {
-  if (stream_capturing(s)) return RGP_OK;
+PersistentLaunch::PersistentLaunch(hipStream_t s) : s_(s), dev_(-1), locked_(false), rc_(RGP_OK) {
+  if (stream_capturing(s)) return;
   int dev = 0;
-  RGP_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return RGP_OK;
-  std::lock_guard<std::mutex> lock(g_guard.mu);
-  if (g_guard.recorded[dev]) RGP_HIP(hipStreamWaitEvent(s, g_guard.ev[dev], 0));
+  if (hipGetDevice(&dev) != hipSuccess) { rc_ = set_err(RGP_EHIP, "persistent launch: hipGetDevice failed"); return; }
+  if (dev < 0 || dev >= 64) return;
+  g_guard.mu.lock();                      // held until the destructor: wait-event, launch and record are one critical section
+  locked_ = true;
+  dev_ = dev;
+  if (g_guard.recorded[dev]) {
+    const hipError_t e = hipStreamWaitEvent(s, g_guard.ev[dev], 0);
+    if (e != hipSuccess) rc_ = set_err(RGP_EHIP, "persistent launch: hipStreamWaitEvent: %s", hipGetErrorString(e));
+  }
+}
+
+int PersistentLaunch::commit() {
+  if (!locked_) return RGP_OK;
+  if (!g_guard.ev[dev_]) RGP_HIP(hipEventCreateWithFlags(&g_guard.ev[dev_], hipEventDisableTiming));
+  RGP_HIP(hipEventRecord(g_guard.ev[dev_], s_));
+  g_guard.recorded[dev_] = true;
   return RGP_OK;
 }
 
-int persistent_guard_end(hipStream_t s) {
-  if (stream_capturing(s)) return RGP_OK;
-  int dev = 0;
-  RGP_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return RGP_OK;
-  std::lock_guard<std::mutex> lock(g_guard.mu);
-  if (!g_guard.ev[dev]) RGP_HIP(hipEventCreateWithFlags(&g_guard.ev[dev], hipEventDisableTiming));
-  RGP_HIP(hipEventRecord(g_guard.ev[dev], s));
-  g_guard.recorded[dev] = true;
-  return RGP_OK;
+PersistentLaunch::~PersistentLaunch() {
+  if (locked_) g_guard.mu.unlock();
 }
 
 thread_local char g_err[512] = "";

@@ -161,7 +161,8 @@ int seq_persistent(rgp_grcn* g, hipStream_t s) {
   p.skip_member = (g->fault & 1) ? 7 : -1;
   g->fault &= ~1;
   RGP_REQUIRE(g->gzr.K == 9 * S && g->gc.K == 9 * S && g->gzr.chunk_major == 0, "convgru_seq: unexpected filter packing");
-  RGP_TRY(persistent_guard_begin(s));
+  PersistentLaunch guard(s);
+  RGP_TRY(guard.status());
   if (g->seq_nc == 1) {
     RGP_TRY(ensure_dyn_smem((const void*)convgru_seq_kernel<4>, SEQ_SMEM));
     convgru_seq_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
@@ -170,7 +171,7 @@ int seq_persistent(rgp_grcn* g, hipStream_t s) {
     convgru_seq_kernel<7><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(p);
   }
   RGP_HIP(hipGetLastError());
-  return persistent_guard_end(s);
+  return guard.commit();
 }
 
 template <typename T>

@@ -211,7 +211,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     q.skip_member = (g->fault & 2) ? 7 : -1;
     g->fault &= ~2;
     RGP_REQUIRE(b->b_c.K == 9 * S && b->b_zr.K == 18 * S, "convgru_bptt: unexpected filter packing");
-    RGP_TRY(persistent_guard_begin(s));
+    PersistentLaunch guard(s);
+    RGP_TRY(guard.status());
     if (g->seq_nc == 1) {
       RGP_TRY(ensure_dyn_smem((const void*)convgru_bptt_kernel<4>, SEQ_SMEM));
       convgru_bptt_kernel<4><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(q);
@@ -220,7 +221,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       convgru_bptt_kernel<7><<<g->seq_groups * 8, SEQ_NT, SEQ_SMEM, s>>>(q);
     }
     RGP_HIP(hipGetLastError());
-    RGP_TRY(persistent_guard_end(s));
+    RGP_TRY(guard.commit());
   }
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;

@@ -55,12 +55,26 @@ int device_cu_count(int* n_cu);
 
 // The persistent ConvGRU kernels (convgru_seq.hip.h, convgru_bptt.hip.h) need every workgroup of a launch resident at
 // once: two such launches must never share the device.  Within one process that is enforced here: a launch on stream s
-// is bracketed by persistent_guard_begin / _end, which make s wait for the previous persistent launch of the process on
-// the current device (whatever stream or plan issued it) and record this one.  Skipped while s is being captured (a
-// graph replays on one stream).  Other processes on the same device are outside its reach: the kernels' own time-out
-// (RGP_ETIMEOUT) is what reports those.
-int persistent_guard_begin(hipStream_t s);
-int persistent_guard_end(hipStream_t s);
+// is made inside the life of a PersistentLaunch object, which takes a process-wide lock, makes s wait for the previous
+// persistent launch of the process on the current device (whatever stream, plan or host THREAD issued it), and --
+// commit(), after the launch -- records this one; the lock is held from the wait to the record, so two host threads
+// cannot both pass the wait before either has recorded.  Skipped while s is being captured (a graph replays on one
+// stream).  Other processes on the same device are outside its reach: the kernels' own time-out (RGP_ETIMEOUT) is what
+// reports those.
+class PersistentLaunch {
+ public:
+  explicit PersistentLaunch(hipStream_t s);
+  ~PersistentLaunch();
+  int status() const { return rc_; }   // RGP_OK, or why the wait could not be queued
+  int commit();                        // after the kernel launch: record it
+  PersistentLaunch(const PersistentLaunch&) = delete;
+  PersistentLaunch& operator=(const PersistentLaunch&) = delete;
+ private:
+  hipStream_t s_;
+  int dev_;
+  bool locked_;
+  int rc_;
+};
 
 // Row tables of the filter-gradient kernel (wgrad.hip.h): byte offset of row m = (z*H + y)*W + x of a D x H x W grid
 // from its image in X (z*x_sz + y*x_sy + x*x_sx elements) and in dY (y_org + z*y_sz + y*y_sy + x*y_sx), entries

@@ -119,7 +119,11 @@ class ModelBase(object):
             ck['flip_seed'] = getattr(self, 'flip_seed', None)
             ck['flip_rng_state'] = self.flip_rng.get_state()
         # dropout sites: Philox key + draw counter, so a resumed run continues the mask stream instead of replaying it
-        ck['dropout'] = [{'seed': d.seed, 'draws': d.draws, 'keep_prob': d.keep_prob} for d in self._dropout_sites()]
+        # (the key carries the SAVING rank's offset, models/gaze_rnn.py dropout_seed: the rank is stored so that a loader
+        # on another rank can re-derive its own key instead of copying this one)
+        from .. import dist as rdist
+        ck['dropout'] = [{'seed': d.seed, 'draws': d.draws, 'keep_prob': d.keep_prob, 'rank': rdist.env_world()[0]}
+                         for d in self._dropout_sites()]
         torch.save(ck, path)
         with open(os.path.join(checkpoint_dir, 'checkpoint'), 'w') as f:
             f.write(os.path.basename(path) + '\n')
@@ -137,8 +141,17 @@ class ModelBase(object):
         if ck.get('flip_rng_state') is not None and getattr(self, 'flip_rng', None) is not None:
             self.flip_rng.set_state(ck['flip_rng_state'])
             self.flip_seed = ck.get('flip_seed', getattr(self, 'flip_seed', None))
-        for d, st in zip(self._dropout_sites(), ck.get('dropout', [])):
-            d.seed, d.draws = int(st['seed']), int(st['draws'])
+        sites, saved = self._dropout_sites(), ck.get('dropout', [])
+        if len(saved) != len(sites):
+            raise ValueError('checkpoint holds %d dropout site(s), this model has %d' % (len(saved), len(sites)))
+        from .. import dist as rdist
+        from .gaze_rnn import DROPOUT_RANK_STRIDE
+        rank = rdist.env_world()[0]
+        for d, st in zip(sites, saved):
+            # every rank loads the one saved file: move the key from the saving rank's stream to this rank's, so
+            # data-parallel replicas keep drawing DIFFERENT masks after a resume; the draw counter continues
+            d.seed = (int(st['seed']) + DROPOUT_RANK_STRIDE * (rank - int(st.get('rank', 0)))) & 0x7fffffffffffffff
+            d.draws = int(st['draws'])
         log.info(" [Checkpoint] Successfully loaded from %s", checkpoint_path)
 
     def _dropout_sites(self):

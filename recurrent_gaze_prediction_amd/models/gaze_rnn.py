@@ -43,12 +43,15 @@ class GRUModelConfig(BaseModelConfig):
         self.train_keep_prob = 0.5     # keep_prob single_step feeds when training (gaze_rnn.py:529)
 
 
+DROPOUT_RANK_STRIDE = 0x9E3779B1     # key offset between data-parallel ranks (also used by the checkpoint loader)
+
+
 def dropout_seed(config, salt):
     """Philox key of a model's dropout site: data-parallel ranks must draw DIFFERENT masks (as they mirror different
     clips, flip_seed below), so the rank is mixed in; the key and the draw counter are saved in checkpoints."""
     from .. import dist as rdist
     rank = rdist.env_world()[0]
-    return ((int(getattr(config, 'init_seed', 0)) << 20) + int(salt) + 0x9E3779B1 * rank) & 0x7fffffffffffffff
+    return ((int(getattr(config, 'init_seed', 0)) << 20) + int(salt) + DROPOUT_RANK_STRIDE * rank) & 0x7fffffffffffffff
 
 
 class GazePredictionGRU(ModelBase):

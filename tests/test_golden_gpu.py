@@ -181,9 +181,9 @@ def test_softmax_xent_kernel_known_answers(gpu):
 def _metric_scores(maps, gt, fix, n):
     flat = lambda a: list(np.asarray(a).reshape(n, 49, 49))
     out = {}
-    for metric in ('cc', 'sim', 'AUC_Borji', 'AUC_Judd'):
+    for metric in ('cc', 'sim', 'AUC_Borji', 'AUC_shuffled', 'AUC_Judd', 'NSS'):      # AVAILABLE_METRICS + EXTRA_METRICS
         np.random.seed(7)
-        if metric == 'AUC_Judd':
+        if metric in ('AUC_Judd', 'NSS'):
             out[metric] = float(np.mean([em.saliency_score_single(metric, m, g, f) for m, g, f in zip(flat(maps), flat(gt), flat(fix))]))
         else:
             out[metric] = float(em.saliency_score(metric, flat(maps), flat(gt), flat(fix)))

@@ -213,3 +213,44 @@ def test_persistent_launches_from_two_streams_are_serialised(gpu):
     for i in range(2):
         engs[i].status()
         assert torch.equal(outs[i], ref[i]), i
+
+
+def test_persistent_launches_from_two_host_threads_are_serialised(gpu):
+    """ctypes releases the GIL inside a library call, so two Python threads (each on its own stream and
+    plan) can be inside rgp_grcn_forward together.  The wait for the previous persistent launch, the launch and its
+    record are one critical section (csrc/rgp_host.h PersistentLaunch): neither plan times out, both give their
+    single-thread results."""
+    import threading
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    B, T = 64, 16
+    p = syn.grcn_params(93, T, gru_std=0.05, random_bn=True)
+    xs = [torch.tensor(syn.c3d_features(94 + i, B, T), device=gpu) for i in range(2)]
+    engs = [GrcnEngine(B, T, dtype='bf16', device=gpu) for _ in range(2)]
+    for e in engs:
+        e.set_weights(p)
+    ref = [e.forward(x)[0].clone() for e, x in zip(engs, xs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    outs, errs = [None, None], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                gate.wait()
+                for _ in range(20):
+                    outs[i] = engs[i].forward(xs[i])[0]
+                streams[i].synchronize()
+        except Exception as exc:                              # surfaced below: a thread's exception is otherwise lost
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        engs[i].status()
+        assert torch.equal(outs[i], ref[i]), i

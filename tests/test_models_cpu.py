@@ -44,3 +44,61 @@ def test_synthetic_dataset_contract():
     assert maps.shape == (2, 4, 49, 49) and fix.shape == (2, 4, 49, 49) and c3d.shape == (2, 4, 512, 2, 7, 7)
     assert pupils.shape == (2, 4) and len(names) == 2 and (maps.reshape(8, -1).sum(-1) > 0).all()
     assert (c3d >= 0).all() and 0.3 < (c3d == 0).mean() < 0.7             # post-ReLU features
+
+
+class _Site(object):
+    def __init__(self, seed):
+        self.seed, self.draws, self.keep_prob = seed, 0, 0.5
+
+
+def _stub_model(tmp_path, n_sites=1):
+    """ModelBase with host-only state: exercises the checkpoint logic without a device engine."""
+    from recurrent_gaze_prediction_amd.models.base import ModelBase
+    from recurrent_gaze_prediction_amd.models.gaze_rnn import GRUModelConfig, dropout_seed
+
+    class Stub(ModelBase):
+        def __init__(self, config):
+            self.config = config
+            ModelBase.__init__(self, config)
+            self.vars = {'w': np.arange(4, dtype=np.float32)}
+            self.sites = [_Site(dropout_seed(config, 17 + i)) for i in range(n_sites)]
+
+        def state_dict(self):
+            return dict(self.vars)
+
+        def load_state_dict(self, state):
+            self.vars = dict(state)
+
+        def _dropout_sites(self):
+            return self.sites
+
+        def _optimizer_engines(self):
+            return []
+
+    c = GRUModelConfig()
+    c.train_dir = str(tmp_path)
+    return Stub(c)
+
+
+def test_checkpoint_resume_keeps_dropout_streams_distinct_per_rank(tmp_path, monkeypatch):
+    """every rank loads the ONE saved file; the Philox key must move to the loading rank's stream
+    (models/gaze_rnn.py dropout_seed mixes the rank in) while the draw counter continues."""
+    import pytest
+    monkeypatch.setenv('RANK', '0')
+    m0 = _stub_model(tmp_path / 'a')
+    m0.sites[0].draws = 5
+    path = m0.save_model_checkpoint(m0.train_dir)
+    keys = {}
+    for rank in (0, 1, 3):
+        monkeypatch.setenv('RANK', str(rank))
+        m = _stub_model(tmp_path / ('r%d' % rank))
+        fresh = m.sites[0].seed                              # what configure() derives on this rank
+        m.sites[0].seed = 0
+        m.load_model_from_checkpoint_file(path)
+        assert m.sites[0].seed == fresh and m.sites[0].draws == 5
+        keys[rank] = m.sites[0].seed
+    assert len(set(keys.values())) == 3
+    monkeypatch.setenv('RANK', '0')
+    two = _stub_model(tmp_path / 'two', n_sites=2)
+    with pytest.raises(ValueError, match='dropout site'):
+        two.load_model_from_checkpoint_file(path)
