@@ -40,6 +40,7 @@ HEAD_FLOPS = {'proj': 51.38e6, 'xconv': 173.41e6, 'convgru_seq': 43.35e6, 'head'
 HEAD_FLOPS_FRAME = 432.79e6
 C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+PMC_SUMMARY = 'profiles/r04_pmc_summary.json'      # separate rocprofv3 --pmc passes of the default command (scripts/r04_profiles.sh)
 
 
 def parse():
@@ -60,6 +61,10 @@ def parse():
                     help="after the headline timing also time BASELINE config 4's data-parallel training step (B=8 x T=35 per "
                          "GPU: fwd + bwd + bucketed RCCL all-reduce + clip + Adam) and report it under 'dp_train'; auto = when "
                          "more than one rank runs, so that the driver's N>1 command exercises the collective path")
+    ap.add_argument('--dp-finetune-probe', choices=['auto', 'on', 'off'], default='auto',
+                    help="also time BASELINE config 5's data-parallel JOINT training step at its per-GPU shape (16 clips x T=35: "
+                         "C3D + cascade, the gradient leaving in nine buckets on a side stream under the backward) with and "
+                         "without the all-reduce, reported under 'dp_finetune'; auto = when more than one rank runs")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline budget')
     ap.add_argument('--cpu-threads', type=int, default=16, help='host threads for the CPU baseline')
@@ -201,6 +206,12 @@ def main():
     dp_train = None
     if args.dp_train_probe == 'on' or (args.dp_train_probe == 'auto' and world > 1):
         dp_train = rdist.dp_train_probe(dist, dev, rank=rank, batch=8, n_steps=35, steps=max(5, args.steps), warmup=2, dtype=args.dtype)
+    # ... and the one place the design overlaps communication with compute: config 5's joint step (122.7 MB of conv + head
+    # gradient buckets + the cascade's 216 MB), timed with and without the collectives
+    dp_finetune = None
+    if args.dp_finetune_probe == 'on' or (args.dp_finetune_probe == 'auto' and world > 1):
+        # (the headline's engines stay alive next to it: 25 GB + the probe's 45 GB of the 288 GB)
+        dp_finetune = rdist.dp_finetune_probe(dist, dev, rank=rank, batch=16, n_steps=35, steps=3, warmup=1, dtype=args.dtype)
 
     if rank == 0:
         frames_total = world * F * args.steps
@@ -230,20 +241,28 @@ def main():
         # (scripts/r03_profiles.sh -> scripts/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction;
         # Infinity-Cache hits are counted, so it is traffic beyond L2, an upper bound of HBM bytes); any other invocation
         # reports null.
-        traffic = None
+        traffic, traffic_stale = None, None
         if c3d is not None and args.workload == 'e2e' and min(args.c3d_chunk, F) == 1024:
             try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_summary.json')) as fh:
+                from recurrent_gaze_prediction_amd import _lib as rlib
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)) as fh:
                     pmc = json.load(fh)
                 stem = ','.join(kname.replace(' ', '').split(',')[:4])      # kernel<CIN,NOUT,HW,D
                 hit = [v for k, v in pmc.items() if ','.join(k.replace(' ', '').split(',')[:4]) == stem and 'hbm_bytes_per_launch' in v]
-                if len(hit) == 1:
+                # the counters belong to the build they were taken with: compare the sources of this kernel
+                then = pmc.get('_meta', {}).get('kernel_source_hashes', {})
+                now = rlib.kernel_source_hashes()
+                files = rlib.KERNEL_SOURCES.get(kname.split('<')[0], tuple(now))
+                traffic_stale = not then or any(then.get(f) != now.get(f) for f in files)
+                if len(hit) == 1 and not traffic_stale:
                     traffic = round(hit[0]['hbm_bytes_per_launch'] / 1e9, 3)      # GB per launch
             except (OSError, ValueError):
-                traffic = None
+                traffic, traffic_stale = None, True         # no summary of this round's build yet
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                     'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_unit': 'GB per launch',
-                    'traffic_profile': 'profiles/r03_pmc_summary.json (separate rocprofv3 --pmc passes of this command)',
+                    'traffic_profile': PMC_SUMMARY + ' (separate rocprofv3 --pmc passes of this command; null + traffic_stale '
+                                       'when the kernel\'s sources have changed since)',
+                    'traffic_stale': traffic_stale,
                     'kernel': kname,
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
                     'algorithmic_gflop_per_launch': round(flops / max(calls, 1) / 1e9, 3)}
@@ -282,6 +301,8 @@ def main():
         }
         if dp_train is not None:
             out['dp_train'] = dp_train
+        if dp_finetune is not None:
+            out['dp_finetune'] = dp_finetune
         if world == 1 and not args.no_cpu_baseline and args.workload in ('e2e', 'head'):
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
@@ -289,9 +310,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if dp_train is not None and (dp_train['ranks_seen'] != args.gpus or not dp_train['replicas_in_sync']):
-        raise SystemExit('bench.py: the data-parallel probe saw %d ranks for --gpus %d (replicas in sync: %s)'
-                         % (dp_train['ranks_seen'], args.gpus, dp_train['replicas_in_sync']))
+    for probe in (dp_train, dp_finetune):
+        if probe is not None and (probe['ranks_seen'] != args.gpus or not probe['replicas_in_sync']):
+            raise SystemExit('bench.py: a data-parallel probe saw %d ranks for --gpus %d (replicas in sync: %s)'
+                             % (probe['ranks_seen'], args.gpus, probe['replicas_in_sync']))
 
 
 if __name__ == '__main__':

@@ -143,6 +143,16 @@ int rgp_grcn_backward(rgp_grcn_t* plan, const float* logits, const float* probs,
 int rgp_grcn_backward_from_states(rgp_grcn_t* plan, const float* d_states, const rgp_grcn_weights* grads,
                                   rgp_stream_t stream);
 
+/* Data-parallel training: rgp_grcn_backward / _from_states record an event on their stream once a group
+ * of gradients is final, in this order -- RGP_GRCN_GRADS_TOP: bn_gamma, bn_beta, up_weight1..3, out_W, out_b (before
+ * the BPTT starts); RGP_GRCN_GRADS_GRU: the six ConvGRU filters; RGP_GRCN_GRADS_PROJ: proj_c3d_W / _b (the end of the
+ * backward).  rgp_grcn_wait_grads makes `waiting_stream` wait for that event, so the host can issue the all-reduce
+ * of the group's slice there while the rest of the backward is still running.  RGP_ESTATE before the first backward. */
+#define RGP_GRCN_GRADS_TOP 0
+#define RGP_GRCN_GRADS_GRU 1
+#define RGP_GRCN_GRADS_PROJ 2
+int rgp_grcn_wait_grads(rgp_grcn_t* plan, int group, rgp_stream_t waiting_stream);
+
 /* After rgp_grcn_backward: the gradient w.r.t. the network input, d_rows [B*T*49, 1024] fp32 in the column
  * order of the conv5b rows (d*512 + c) -- what rgp_c3d_backward takes when the conv stack is fine-tuned
  * end to end (BASELINE config 5). */

@@ -20,6 +20,7 @@ RGP_ETIMEOUT = -5
 RGP_GRCN_SAVE_FOR_BACKWARD, RGP_GRCN_PER_STEP = 1, 2
 RGP_C3D_SAVE_FOR_BACKWARD, RGP_C3D_KERNELS_IGEMM, RGP_C3D_KERNELS_TILE128 = 1, 2, 4
 RGP_FAULT_SEQ_LOST_MEMBER, RGP_FAULT_BPTT_LOST_MEMBER = 1, 2
+RGP_GRCN_GRADS_TOP, RGP_GRCN_GRADS_GRU, RGP_GRCN_GRADS_PROJ = 0, 1, 2
 RGP_SQNORM_PARTIALS = 256          # include/rgp.h
 DTYPES = {'f32': RGP_F32, 'fp32': RGP_F32, 'float32': RGP_F32, 'bf16': RGP_BF16, 'bfloat16': RGP_BF16}
 
@@ -147,6 +148,7 @@ SIGNATURES = {
     'rgp_fcgru_set_dropout': (c_int, [c_void_p, ctypes.c_float, c_void_p]),
     'rgp_cascade_set_dropout': (c_int, [c_void_p, ctypes.c_float, c_void_p]),
     'rgp_c3d_wait_layer_grads': (c_int, [c_void_p, c_int, c_void_p]),
+    'rgp_grcn_wait_grads': (c_int, [c_void_p, c_int, c_void_p]),
     'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
     'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),
@@ -173,6 +175,29 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def kernel_source_hashes():
+    """{file name: sha256[:16]} of the library's sources (csrc/ + include/rgp.h).  A PMC summary records them
+    (scripts/pmc_summary.py) and bench.py compares: counters taken from another build of a kernel are reported as stale."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, 'csrc', '*.hip')) + glob.glob(os.path.join(here, 'csrc', '*.h')))
+    files.append(os.path.join(os.path.dirname(here), 'include', 'rgp.h'))
+    out = {}
+    for f in files:
+        if os.path.exists(f):
+            with open(f, 'rb') as fh:
+                out[os.path.basename(f)] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out
+
+
+# sources that define a kernel's code and launch geometry (prefix of the name rgp_c3d_layer_kernel_name returns)
+KERNEL_SOURCES = {
+    'conv_patch_bf16_kernel': ('conv_patch.hip.h', 'rgp_conv_patch.hip', 'rgp_c3d.hip', 'rgp_c3d_plan.h', 'rgp_host.h'),
+    'conv_patch14_bf16_kernel': ('conv_patch14.hip.h', 'rgp_conv_patch.hip', 'rgp_c3d.hip', 'rgp_c3d_plan.h', 'rgp_host.h'),
+}
 
 
 def check(rc):

@@ -30,6 +30,13 @@ struct GrcnBwd {
   Buf xch_c, xch_z, xch_r, bptt_cnt;       // persistent BPTT kernel (convgru_bptt.hip.h): exchange images + phase counters
   Buf hp_all, rhp_all, dzb, ptoep, sq_partial;   // dzb / ptoep: blocked dz and the Toeplitz partial sums of the head filter gradient     // halo-padded h_{t-1} and r.h_{t-1} of every step, [t][b][9][9][S] (wgrad operands)
   rgp_grcn_weights w;   // forward weights (device fp32) as last set
+  // recorded by backward_impl once a group of gradients is final (rgp_grcn_wait_grads): 0 = batch-norm + upsampling +
+  // output layer, 1 = the six ConvGRU filters, 2 = the projection (= end of the backward)
+  hipEvent_t grad_ev[3] = {nullptr, nullptr, nullptr};
+  bool grad_ev_made = false, grad_ev_recorded = false;
+  ~GrcnBwd() {
+    if (grad_ev_made) for (int i = 0; i < 3; ++i) (void)hipEventDestroy(grad_ev[i]);
+  }
 };
 
 namespace {
@@ -92,6 +99,13 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   auto I = [&](size_t off) { return (const int*)(ws + off); };
   auto Fp = [&](const Buf& x) { return (float*)(ws + x.off); };
   auto Tp = [&](const Buf& x) { return (T*)(ws + x.off); };
+  if (!b->grad_ev_made) {
+    for (int i = 0; i < 3; ++i) RGP_HIP(hipEventCreateWithFlags(&b->grad_ev[i], hipEventDisableTiming));
+    b->grad_ev_made = true;
+  }
+  // (not while `s` is being captured into a graph: a replay runs on one stream and has nobody to signal)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool mark = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone);
 
   // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
   // slices of one flat buffer (engine.py: flat_grads), else one per tensor
@@ -194,6 +208,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const float inv = 1.0f / sqrtf(1.0f + 1e-3f);
   bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(Fp(b->dy), Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma,
                                                   (float*)gr->bn_beta, Fp(b->dh_head), B, T_, S, inv);
+  if (mark) RGP_HIP(hipEventRecord(b->grad_ev[0], s));                 // bn_gamma/beta, up_weight1..3, out_W, out_b are final
   // 6. BPTT: t = T-1 .. 0 -- one persistent launch where the plan allows it (bf16, the reference cell, <= 64 clips)
   const int ew_blocks = (int)std::min<size_t>((st + 255) / 256, 4096);
   const bool persistent = sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1);
@@ -287,6 +302,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       p.zy[q] = (long long)q * S * sizeof(T); p.zw[q] = dWh[q] - dWh[0];
     }
     RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    if (mark) RGP_HIP(hipEventRecord(b->grad_ev[1], s));               // the six ConvGRU filters are final
   }
   {  // projection: one row per (frame, position), X = the 1024-channel C3D rows, dY = dE behind its zero row
     WgradParams p = wg_params();
@@ -297,6 +313,10 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_TRY((launch_wgrad<T, 1>(p, s)));
     dense_colsum_kernel<T><<<(int)std::min<long long>((M + 63) / 64, 1024), 256, 0, s>>>(Tp(b->dE) + P, M, P, (float*)gr->proj_c3d_b);
     RGP_HIP(hipGetLastError());
+  }
+  if (mark) {
+    RGP_HIP(hipEventRecord(b->grad_ev[2], s));
+    b->grad_ev_recorded = true;
   }
   return RGP_OK;
 }
@@ -481,6 +501,14 @@ int rgp_grcn_backward_from_states(rgp_grcn_t* g, const float* d_states, const rg
   hipStream_t s = (hipStream_t)stream;
   return g->dtype == RGP_BF16 ? backward_impl<bf16_t>(g, nullptr, nullptr, nullptr, grads, 0, s, d_states)
                               : backward_impl<float>(g, nullptr, nullptr, nullptr, grads, 0, s, d_states);
+}
+
+int rgp_grcn_wait_grads(rgp_grcn_t* g, int group, rgp_stream_t waiting_stream) {
+  RGP_REQUIRE(g && group >= 0 && group <= 2, "rgp_grcn_wait_grads: bad arguments");
+  if (!g->save || !g->bwd || !g->bwd->grad_ev_recorded)
+    return set_err(RGP_ESTATE, "rgp_grcn_wait_grads: no backward has run on this plan");
+  RGP_HIP(hipStreamWaitEvent((hipStream_t)waiting_stream, g->bwd->grad_ev[group], 0));
+  return RGP_OK;
 }
 
 int rgp_grcn_backward_input(rgp_grcn_t* g, float* d_rows, rgp_stream_t stream) {

@@ -125,11 +125,13 @@ class GradBucketReducer(object):
         self.avg = dist is not None and _backend(dist) == 'nccl'
         self.pending = []
         self.bytes_reduced = 0
+        self.buckets_reduced = 0
 
     def reduce(self, bucket, ready=None):
         if self.dist is None:
             return
         self.bytes_reduced += bucket.numel() * bucket.element_size()
+        self.buckets_reduced += 1
         op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
         if self.stream is not None:
             if ready is not None:
@@ -143,6 +145,12 @@ class GradBucketReducer(object):
             self.dist.all_reduce(bucket, op=op)
             if not self.avg:
                 bucket.div_(self.dist.get_world_size())
+
+    def reduce_buckets(self, buckets):
+        """buckets: [(slice, ready)] in completion order (GrcnEngine.grad_buckets()); `ready` is ignored off the GPU,
+        where the producer has finished by the time reduce() runs."""
+        for bucket, ready in buckets:
+            self.reduce(bucket, ready=ready if self.stream is not None else None)
 
     def finish(self):
         if self.dist is None:
@@ -167,19 +175,46 @@ def ranks_seen(dist, rank, device='cpu'):
     return len(set(int(t.item()) for t in got))
 
 
-def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2, dtype='bf16', seed=0):
+def all_ranks_ok(dist, ok, device='cpu'):
+    """True iff `ok` holds on EVERY rank (one MIN all-reduce): lets all ranks leave together instead of one raising
+    while its peers block in the next collective."""
+    if dist is None:
+        return bool(ok)
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def engine_status_all_ranks(dist, engine, device):
+    """engine.status() on every rank, agreed: raises on ALL ranks if any rank's persistent ConvGRU launch timed out."""
+    err = None
+    try:
+        engine.status()
+    except Exception as exc:                    # RgpError(RGP_ETIMEOUT)
+        err = exc
+    if not all_ranks_ok(dist, err is None, device):
+        raise err if err is not None else RuntimeError('a peer rank reported a failed persistent ConvGRU launch')
+
+
+def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2, dtype='bf16', seed=0, per_step=False):
     """BASELINE config 4 at its per-GPU shape (B = 8 clips x T = 35 per rank) as ONE data-parallel training step:
     gaze_grcn forward + backward on the rank's own clips -> GradBucketReducer (the flat 12 MB fp32 gradient, RCCL AVG
     on a side stream) -> finish -> clip_by_global_norm(10) + TF-Adam (base.py:286-297).  Timed like the headline
     (barrier, `steps` steps, barrier, MAX over ranks).  Every rank starts from the same weights and sees different
     clips, so after the steps the weights must still be identical on all ranks -- checked with a MAX/MIN all-reduce of
-    a checksum.  Returns a dict (same on every rank)."""
+    a checksum.  Returns a dict (same on every rank).
+
+    The gradient goes out as THREE buckets in the order the backward finishes them (GrcnEngine.grad_buckets: batch-norm +
+    upsampling + output layer before the BPTT starts, the ConvGRU filters, the projection), so only the last 2.1 MB
+    start after the backward has ended.  per_step=True: ConvGRU recurrence and BPTT as per-timestep launches
+    (RGP_GRCN_PER_STEP) -- REQUIRED when several ranks share one device (tests), where two persistent launches would
+    compete for the CUs (include/rgp.h)."""
     import time
     from . import synthetic as syn
     from .engine import GrcnEngine
     dev = torch.device(device)
     world = dist.get_world_size() if dist is not None else 1
-    head = GrcnEngine(batch, n_steps, dtype=dtype, save_for_backward=True, device=dev)
+    head = GrcnEngine(batch, n_steps, dtype=dtype, save_for_backward=True, device=dev, per_step=per_step)
     head.set_weights(syn.grcn_params(seed + 1, n_steps))
     g = torch.Generator(device=dev)
     g.manual_seed(4321 + int(rank))
@@ -195,7 +230,7 @@ def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2,
     def step():
         head.forward(x, out_logits=logits, out_probs=probs)
         head.backward(logits, probs, gt)
-        reducer.reduce(head.flat_grads)
+        reducer.reduce_buckets(head.grad_buckets())
         reducer.finish()
         gnorm[0] = head.adam_step(k[0], 1e-4 * 0.8 ** (k[0] // 500), max_grad_norm=10.0)
         k[0] += 1
@@ -209,7 +244,7 @@ def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2,
         step()
     barrier(dist, dev)
     elapsed = max_over_ranks(dist, time.perf_counter() - t0, dev)
-    head.status()
+    engine_status_all_ranks(dist, head, dev)
     seen = ranks_seen(dist, rank, dev)
     # replicas stay replicas: same weights on every rank after the averaged steps
     chk = float(head.flat_params.double().abs().sum().item())
@@ -221,5 +256,78 @@ def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2,
             'ms_per_step': round(elapsed / steps * 1e3, 4),
             'frames_per_s': round(world * batch * n_steps * steps / elapsed, 1),
             'allreduce_bytes_per_step': int((reducer.bytes_reduced - bytes0) // max(steps, 1)),
+            'allreduce_buckets_per_step': 3, 'convgru': 'per-step launches' if per_step else 'persistent',
             'backend': _backend(dist), 'ranks_seen': seen, 'world': world,
             'grad_norm_last': float(gnorm[0].item()), 'replicas_in_sync': bool(abs(hi - lo) <= 1e-9 * max(abs(hi), 1.0))}
+
+
+def dp_finetune_probe(dist, device, rank=0, batch=16, n_steps=35, steps=3, warmup=1, dtype='bf16', seed=0, c3d_chunk=None,
+                      model='cascade'):
+    """BASELINE config 5 at its per-GPU shape (16 clips x T = 35 per rank = 560 C3D windows) as ONE data-parallel
+    training step: C3D forward -> cascade forward -> l2 loss -> cascade backward -> conv-stack backward, the gradient
+    leaving in NINE buckets through GradBucketReducer's side stream as their producers are queued (the cascade's
+    216 MB first, then conv5b ... conv1a, 110.6 MB: SURVEY 8e) -> finish -> global-norm clip over ALL variables +
+    TF-Adam (base.py:286-297).  model='grcn': the gaze_grcn head instead of the cascade (its three head buckets + the
+    eight conv buckets), for boxes short of memory.
+
+    Timed like the headline (barrier, `steps` steps, barrier, MAX over ranks), then -- after the replicas' weights
+    have been compared -- the same steps once more WITHOUT the reducer ('ms_per_step_no_allreduce': the replicas
+    drift apart there, which is why it runs last): the difference is the communication the overlap did not hide."""
+    import time
+    from .finetune import EndToEndCascade, EndToEndGaze
+    dev = torch.device(device)
+    world = dist.get_world_size() if dist is not None else 1
+    F = batch * n_steps
+    chunk = min(c3d_chunk or F, F)
+    g = torch.Generator(device=dev)
+    g.manual_seed(977 + int(rank))
+    video = torch.rand(F, 16, 112, 112, 3, device=dev, generator=g) - 0.5
+    gt = torch.rand(batch, n_steps, 49, 49, device=dev, generator=g) + 1e-3
+    if model == 'cascade':
+        m = EndToEndCascade(batch, n_steps, dtype=dtype, device=dev, max_windows=chunk, seed=seed + 1)
+        frames = torch.rand(batch, n_steps, 98, 98, 3, device=dev, generator=g)
+        run = lambda: m.train_step(video, frames, gt, 1e-4)
+    else:
+        m = EndToEndGaze(batch, n_steps, dtype=dtype, device=dev, max_windows=chunk, seed=seed + 1)
+        gt = (gt / gt.sum((-1, -2), keepdim=True)).contiguous()
+        run = lambda: m.train_step(video, gt, 1e-4)
+    m.attach_process_group(dist)
+    last = [None, None]
+
+    def timed(k):
+        barrier(dist, dev)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            last[0], last[1] = run()
+        barrier(dist, dev)
+        return max_over_ranks(dist, time.perf_counter() - t0, dev)
+
+    for _ in range(warmup):
+        run()
+    bytes0, n0 = m.reducer.bytes_reduced, m.reducer.buckets_reduced
+    elapsed = timed(steps)
+    per_step_bytes = int((m.reducer.bytes_reduced - bytes0) // max(steps, 1))
+    per_step_buckets = int((m.reducer.buckets_reduced - n0) // max(steps, 1))
+    finite = bool(torch.isfinite(last[0])) and bool(torch.isfinite(last[1]))
+    chk = float(sum(e.flat_params.double().abs().sum().item() for e in m.engines))
+    hi = max_over_ranks(dist, chk, dev)
+    lo = -max_over_ranks(dist, -chk, dev)
+    seen = ranks_seen(dist, rank, dev)
+    # the same steps with the collectives switched off (replicas diverge from here on: nothing may follow that needs them)
+    m.attach_process_group(None)
+    run()
+    elapsed_off = timed(steps)
+    grad_bytes = int(sum(e.flat_grads.numel() * 4 for e in m.engines))
+    return {'workload': ('C3D conv stack + %s, data-parallel JOINT TRAINING step (BASELINE config 5 per-GPU shape): fwd + bwd, '
+                         'gradient buckets all-reduced (mean) on a side stream as their producers are queued, then '
+                         'clip_by_global_norm(10) over all variables + TF-Adam'
+                         % ('gaze_grcn_cascade' if model == 'cascade' else 'gaze_grcn head')),
+            'clips_per_gpu': batch, 'n_lstm_steps': n_steps, 'windows_per_gpu': F, 'c3d_chunk': chunk, 'steps': steps,
+            'warmup': warmup, 'dtype': dtype,
+            'ms_per_step': round(elapsed / steps * 1e3, 3),
+            'ms_per_step_no_allreduce': round(elapsed_off / steps * 1e3, 3),
+            'exposed_allreduce_ms_per_step': round((elapsed - elapsed_off) / steps * 1e3, 3),
+            'frames_per_s': round(world * F * steps / elapsed, 1),
+            'allreduce_bytes_per_step': per_step_bytes, 'allreduce_buckets_per_step': per_step_buckets,
+            'gradient_bytes': grad_bytes, 'backend': _backend(dist), 'ranks_seen': seen, 'world': world,
+            'finite': finite, 'replicas_in_sync': bool(abs(hi - lo) <= 1e-9 * max(abs(hi), 1.0))}

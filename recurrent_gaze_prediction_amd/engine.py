@@ -231,6 +231,31 @@ class GrcnEngine(object):
                                                   {'xentropy': 0, 'l2': 1}[loss_type], _stream_ptr(self.device)))
         return self.grads
 
+    # gradient groups in the order the backward finishes them (rgp_grcn_wait_grads); each is one contiguous slice of
+    # flat_grads because GRCN_PARAM_TO_FIELD lists the variables in this order
+    GRAD_GROUPS = ((_lib.RGP_GRCN_GRADS_TOP, 'bn_gamma', 'out_b'),
+                   (_lib.RGP_GRCN_GRADS_GRU, 'GRU_Conv_Wz', 'GRU_Conv_U'),
+                   (_lib.RGP_GRCN_GRADS_PROJ, 'proj_c3d_W', 'proj_c3d_b'))
+
+    def grad_buckets(self):
+        """[(slice of flat_grads, ready)] in completion order: `ready(stream)` makes a torch.cuda.Stream wait until the
+        last backward() has finished that slice (data-parallel training: the all-reduce of the upsampling / output
+        gradients runs under the BPTT, that of the ConvGRU filters under the projection's filter gradient)."""
+        names = list(GRCN_PARAM_TO_FIELD)
+        offs, off = {}, 0
+        for k in names:
+            offs[k] = (off, off + self.grads[k].numel())
+            off += self.grads[k].numel()
+        out = []
+        for group, first, last in self.GRAD_GROUPS:
+            assert names.index(first) <= names.index(last)
+            lo, hi = offs[first][0], offs[last][1]
+            out.append((self.flat_grads[lo:hi],
+                        lambda stream, group=group: _lib.check(self.lib.rgp_grcn_wait_grads(
+                            self._h, group, ctypes.c_void_p(stream.cuda_stream)))))
+        assert sum(b.numel() for b, _ in out) == self.flat_grads.numel()
+        return out
+
     def backward_input(self, out=None):
         """After backward(): d loss / d input as conv5b rows [B*T*49, 1024] fp32 (column d*512+c), the
         gradient C3DEngine.backward(d_rows=...) consumes when the conv stack is fine-tuned."""

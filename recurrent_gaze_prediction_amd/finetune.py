@@ -36,12 +36,14 @@ def _c3d_backward_chunks(m, video, d_rows, reducer):
 
 class EndToEndGaze(object):
     def __init__(self, batch, n_steps, dtype='bf16', device='cuda:0', max_windows=None, seed=0, c3d_params=None,
-                 grcn_params=None, loss_type='xentropy'):
+                 grcn_params=None, loss_type='xentropy', per_step=False):
+        """per_step=True: the head's ConvGRU recurrence and BPTT as per-timestep launches (RGP_GRCN_PER_STEP) -- needed
+        when several processes share one device, where two persistent launches would compete for the CUs."""
         self.B, self.T, self.F = int(batch), int(n_steps), int(batch) * int(n_steps)
         self.loss_type = loss_type
         self.device = torch.device(device)
         self.c3d = C3DEngine(min(self.F, max_windows or self.F), dtype=dtype, device=device, save_for_backward=True)
-        self.head = GrcnEngine(self.B, self.T, dtype=dtype, save_for_backward=True, device=device)
+        self.head = GrcnEngine(self.B, self.T, dtype=dtype, save_for_backward=True, device=device, per_step=per_step)
         self.c3d.set_weights(c3d_params if c3d_params is not None else synthetic.c3d_params(seed))
         self.head.set_weights(grcn_params if grcn_params is not None else synthetic.grcn_params(seed + 1, self.T))
         self.rows = torch.empty(self.F * 49, 1024, dtype=self.c3d.torch_dtype, device=self.device)
@@ -84,7 +86,7 @@ class EndToEndGaze(object):
             loss = l2_loss(logits, labels, self.F)
         self.head.backward(logits, probs, labels, self.loss_type)
         if red is not None:
-            red.reduce(self.head.flat_grads)          # 12 MB over xGMI while the conv stack differentiates
+            red.reduce_buckets(self.head.grad_buckets())   # 12 MB in three buckets (the first leaves before the BPTT)
         self.head.backward_input(self.d_rows)
         _c3d_backward_chunks(self, video, self.d_rows, red)
         if red is not None and finish:

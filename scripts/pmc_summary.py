@@ -36,8 +36,12 @@ def main():
             # GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES sums busy cycles over all SIMDs (256 CUs x 4)
             e['mfma_pipe_duty'] = m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)
         out[k] = e
+    # which build these counters belong to (bench.py reports them as stale once a kernel's sources have changed)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from recurrent_gaze_prediction_amd import _lib
+    out['_meta'] = {'kernel_source_hashes': _lib.kernel_source_hashes()}
     json.dump(out, open(os.path.join(root, 'pmc_summary.json'), 'w'), indent=1)
-    for k, e in list(out.items())[:24]:
+    for k, e in [kv for kv in out.items() if kv[0] != '_meta'][:24]:
         print(k)
         for c, v in e.items():
             print('    %-30s %s' % (c, ('%.6g' % v) if isinstance(v, float) else v))

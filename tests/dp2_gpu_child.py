@@ -5,7 +5,10 @@ The REAL engines under world size 2: rank r runs EndToEndGaze on clip r of a 2-c
 bucketed reducer with the library's per-layer events, finish, global-norm clip + Adam); rank 0 also runs the
 single-process step on both clips.  The loss is a sum over clips divided by the clip count (gaze_rnn.py:406-407) and no
 operator couples clips (inference-mode batch-norm), so the mean of the two ranks' gradients is the full-batch gradient
-(base.py:286-292 on the global batch) up to the summation order of the filter gradients.  Rank 0 prints one JSON line."""
+(base.py:286-292 on the global batch) up to the summation order of the filter gradients.  Rank 0 prints one JSON line.
+
+Both ranks sit on ONE device here, the configuration include/rgp.h rules out for the persistent ConvGRU kernels (two
+such launches would compete for the CUs): every head in this file runs its recurrence per step (RGP_GRCN_PER_STEP)."""
 import json
 import os
 import sys
@@ -41,7 +44,7 @@ def main():
         return float(loss), torch.cat([m.c3d.flat_grads, m.head.flat_grads]).double().clone()
 
     # this rank's clip
-    m = EndToEndGaze(1, T, dtype='bf16', device=dev, c3d_params=p3, grcn_params=ph)
+    m = EndToEndGaze(1, T, dtype='bf16', device=dev, c3d_params=p3, grcn_params=ph, per_step=True)
     m.attach_process_group(dist)
     v, lab = video[rank * T:(rank + 1) * T], gt[rank:rank + 1]
     loss_r, g_dp = grads_of(m, v, lab, True)
@@ -52,7 +55,7 @@ def main():
     rdist.barrier(dist, dev)
     out = None
     if rank == 0:
-        ref = EndToEndGaze(B, T, dtype='bf16', device=dev, c3d_params=p3, grcn_params=ph)
+        ref = EndToEndGaze(B, T, dtype='bf16', device=dev, c3d_params=p3, grcn_params=ph, per_step=True)
         loss_ref, g_ref = grads_of(ref, video, gt, False)
         _, gnorm_ref = ref.train_step(video, gt, 1e-4, max_grad_norm=10.0)
         torch.cuda.synchronize()
@@ -66,7 +69,7 @@ def main():
                'bytes_reduced': int(m.reducer.bytes_reduced)}
     rdist.barrier(dist, dev)
     # bench.py's N > 1 leg (dist.dp_train_probe) under world size 2: both ranks must be seen and stay in sync
-    probe = rdist.dp_train_probe(dist, dev, rank=rank, batch=2, n_steps=3, steps=2, warmup=1)
+    probe = rdist.dp_train_probe(dist, dev, rank=rank, batch=2, n_steps=3, steps=2, warmup=1, per_step=True)
     if rank == 0:
         out['probe'] = probe
         print(json.dumps(out))

@@ -33,7 +33,9 @@ def test_default_bench_line_keeps_the_contract(gpu):
     # algorithmic FLOPs of conv2a per launch of 1024 windows: 2 x 16 x 56^2 x 27 x 64 x 128 x 1024
     assert abs(rf['algorithmic_gflop_per_launch'] - 2 * 16 * 56 * 56 * 27 * 64 * 128 * 1024 / 1e9) < 1.0
     # traffic beyond L2 per launch (committed PMC summary): at least the layer's input + output, below 2x of it
-    assert rf['traffic'] is not None and 8.0 < rf['traffic'] < 16.0 and rf['traffic_unit'] == 'GB per launch'
+    # (null + traffic_stale once the kernel's sources differ from the ones the summary was taken with)
+    assert rf['traffic_unit'] == 'GB per launch' and rf['traffic_stale'] in (True, False)
+    assert (rf['traffic'] is None) if rf['traffic_stale'] else (8.0 < rf['traffic'] < 16.0), rf
     cb = d['cpu_baseline']
     assert cb['kind'] in ('port', 'reference') and cb['unit'] == 'frames/s' and cb['cores'] >= 1 and cb['value'] > 0 and cb['sample']
     # the stage timers of the library cover the step

@@ -85,8 +85,8 @@ class Stub(object):
 def train_step(eng, m, v, step, x, y, reducer):
     eng.backward(x, y)
     half = eng.flat_grads.numel() // 2           # two buckets, like the per-layer buckets of the conv stack
-    reducer.reduce(eng.flat_grads[half:])
-    reducer.reduce(eng.flat_grads[:half])
+    # completion order, with `ready` callbacks (ignored off the GPU): GrcnEngine.grad_buckets()'s form
+    reducer.reduce_buckets([(eng.flat_grads[half:], lambda stream: 1 / 0), (eng.flat_grads[:half], None)])
     reducer.finish()
     g, norm = torch_ref.clip_by_global_norm({'w': eng.flat_grads.clone()}, 0.05)
     p, m, v = torch_ref.adam_step_tf({'w': eng.flat_params}, g, m, v, step, 1e-2)
@@ -109,8 +109,10 @@ for step in range(3):
 # the per-rank flip-augmentation seeds differ and are recorded (gaze_rnn.py:504-510 draws from one global RNG)
 from recurrent_gaze_prediction_amd.models import gaze_rnn
 seed = (0 * 1000003 + 7919 * rank + 12345) & 0x7fffffff
+# a failure on ONE rank is seen by all of them (dp_train_probe exits every rank together)
+agree = [rdist.all_ranks_ok(d, True), rdist.all_ranks_ok(d, rank != world - 1 or world == 1)]
 print(json.dumps({'rank': rank, 'world': world, 'W': eng.flat_params.tolist(), 'norms': norms, 'flip_seed': seed,
-                  'bytes': red.bytes_reduced}), flush=True)
+                  'bytes': red.bytes_reduced, 'buckets': red.buckets_reduced, 'agree': agree}), flush=True)
 if d is not None:
     d.barrier(); d.destroy_process_group()
 ''' % ROOT
@@ -139,7 +141,9 @@ def test_two_rank_dp_step_reproduces_the_full_batch_step(tmp_path):
     for r in two:        # every rank ends with the weights of the single-process run on all 8 clips
         assert np.allclose(r['W'], one['W'], rtol=0, atol=1e-12)
         assert np.allclose(r['norms'], one['norms'], rtol=1e-12)      # the clip saw the global-batch gradient
-        assert r['bytes'] == 3 * 24 * 8                               # both buckets, every step, reduced in place
+        assert r['bytes'] == 3 * 24 * 8 and r['buckets'] == 6         # both buckets, every step, reduced in place
+        assert r['agree'] == [True, False]                            # the last rank's failure reaches rank 0 too
+    assert one['agree'] == [True, True]
     assert one['norms'][0] > 0.05                                     # the clip was active
     assert two[0]['flip_seed'] != two[1]['flip_seed']
 
@@ -148,7 +152,8 @@ def test_spawn_ranks_starts_one_process_per_rank(tmp_path):
     """`python bench.py --gpus N` without a launcher goes through dist.spawn_ranks: N fresh ranks, rank 0's stdout
     relayed, the launcher's exit code returned."""
     script = tmp_path / 'echo_rank.py'
-    script.write_text("import os, sys\nprint('RANK %s of %s args %s' % (os.environ['RANK'], os.environ['WORLD_SIZE'], sys.argv[1:]), flush=True)\n"
+    # (one write() per line: print() writes the text and the newline separately, and two ranks share this pipe)
+    script.write_text("import os, sys\nsys.stdout.write('RANK %s of %s args %s\\n' % (os.environ['RANK'], os.environ['WORLD_SIZE'], sys.argv[1:]))\nsys.stdout.flush()\n"
                       "sys.exit(3 if '--fail' in sys.argv and os.environ['RANK'] == '1' else 0)\n")
     code = ("import sys; sys.path.insert(0, %r)\nfrom recurrent_gaze_prediction_amd import dist as rdist\n"
             "sys.exit(rdist.spawn_ranks(2, %r, sys.argv[1:]))\n" % (ROOT, str(script)))

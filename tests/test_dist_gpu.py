@@ -29,6 +29,14 @@ def test_rccl_one_rank_group_runs_the_reducer(gpu):
     pr = out['probe']
     assert pr['backend'] == 'nccl' and pr['ranks_seen'] == 1 and pr['replicas_in_sync'], pr
     assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6 and pr['ms_per_step'] > 0 and pr['grad_norm_last'] > 0, pr
+    assert pr['allreduce_buckets_per_step'] == 3 and pr['convgru'] == 'persistent', pr
+    # config 5's leg: the cascade's flat buffer + eight conv buckets; the gaze_grcn variant: three head + eight conv buckets
+    fp, fg = out['finetune_probe'], out['finetune_probe_grcn']
+    for q, buckets in ((fp, 9), (fg, 11)):
+        assert q['backend'] == 'nccl' and q['ranks_seen'] == 1 and q['replicas_in_sync'] and q['finite'], q
+        assert q['allreduce_buckets_per_step'] == buckets and q['allreduce_bytes_per_step'] == q['gradient_bytes'], q
+        assert q['ms_per_step'] > 0 and q['ms_per_step_no_allreduce'] > 0, q
+    assert fp['gradient_bytes'] > 300e6 and 120e6 < fg['gradient_bytes'] < 125e6, (fp, fg)
 
 
 def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
@@ -49,3 +57,4 @@ def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
     pr = out['probe']
     assert pr['world'] == 2 and pr['ranks_seen'] == 2 and pr['replicas_in_sync'], pr
     assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6, pr
+    assert pr['convgru'] == 'per-step launches', pr
