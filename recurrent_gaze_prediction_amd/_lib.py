@@ -28,7 +28,7 @@ c_void_p, c_int, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_si
 
 
 class RgpError(RuntimeError):
-    pass
+    code = None        # the library's RGP_E* return value, when the error came from a library call
 
 
 class GrcnWeights(ctypes.Structure):
@@ -202,4 +202,6 @@ KERNEL_SOURCES = {
 
 def check(rc):
     if rc != 0:
-        raise RgpError('librgp_hip error %d: %s' % (rc, load().rgp_last_error().decode()))
+        err = RgpError('librgp_hip error %d: %s' % (rc, load().rgp_last_error().decode()))
+        err.code = int(rc)
+        raise err

@@ -168,6 +168,7 @@ class GrcnEngine(object):
         self.device = _require_gpu(device)
         self.B, self.T, self.P, self.S = int(batch), int(n_steps), int(dim_proj), int(dim_state)
         self.dtype = dtype
+        self.per_step, self.save_for_backward = bool(per_step), bool(save_for_backward)
         self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):

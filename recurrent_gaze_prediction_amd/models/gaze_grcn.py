@@ -57,12 +57,34 @@ class GazePredictionGRCN(GazePredictionGRU):
         B, T = model.batch_size, model.n_lstm_steps
         P, S = GazePredictionGRCN.DIM_CNN_PROJ, GazePredictionGRCN.RNN_STATE_SIZE
         engine = GrcnEngine(B, T, P, S, dtype=getattr(model.config, 'compute_dtype', 'bf16'),
-                            save_for_backward=getattr(model.config, 'trainable', True), device=model.session.device)
+                            save_for_backward=getattr(model.config, 'trainable', True), device=model.session.device,
+                            per_step=bool(getattr(model.config, 'convgru_per_step', False)))
         # reference initialisers (gaze_grcn.py:64-81,234-237,292-314); BN gamma=1, beta=0 per step
         model.variables = synthetic.grcn_params(getattr(model.config, 'init_seed', 0), T, P, S, gru_std=1e-4)
         engine.set_weights(model.variables)
         net['variables'] = model.variables
         return engine
+
+    def _recover_from_timeout(self):
+        """A persistent ConvGRU launch lost a group member (another process on the device took its CUs; include/rgp.h):
+        continue on a plan that runs the recurrence and its BPTT as per-timestep launches (RGP_GRCN_PER_STEP), which need no
+        co-residency.  A NEW engine object in this process (never a re-exec): master weights and optimizer slots move
+        over device to device; the poisoned outputs are recomputed by the caller.  Logged once."""
+        from ..engine import OPT_STATE_KEYS
+        old = self.engine
+        if getattr(old, 'per_step', False):
+            return False                                          # already the fallback: the error is something else
+        log = __import__('logging').getLogger('rgp')
+        log.warning('persistent ConvGRU launch timed out (RGP_ETIMEOUT): switching this model to per-timestep launches')
+        new = GrcnEngine(old.B, old.T, old.P, old.S, dtype=old.dtype, save_for_backward=old.save_for_backward,
+                         device=old.device, per_step=True)
+        new.set_weights(old.weights)
+        for k in OPT_STATE_KEYS:
+            if getattr(old, k, None) is not None:
+                setattr(new, k, getattr(old, k).clone())
+        self.engine = new
+        self.config.convgru_per_step = True
+        return True
 
     # ---- variables (TF names), for checkpoints and for loading exported weights ----------
     def state_dict(self):

@@ -54,6 +54,19 @@ def dropout_seed(config, salt):
     return ((int(getattr(config, 'init_seed', 0)) << 20) + int(salt) + DROPOUT_RANK_STRIDE * rank) & 0x7fffffffffffffff
 
 
+class Placeholder(object):
+    """Inert stand-in for a ``tf.placeholder`` attribute of the reference model (gaze_rnn.py:114-129)."""
+
+    def __init__(self, name, shape, dtype='float32'):
+        self.name, self.shape, self.dtype = name, tuple(shape), dtype
+
+    def get_shape(self):
+        return self.shape
+
+    def __repr__(self):
+        return '<Placeholder %s %s %s: feed model.predict(c3d, frames) instead of session.run>' % (self.name, self.shape, self.dtype)
+
+
 class GazePredictionGRU(ModelBase):
     """gaze_rnn.py:66-680."""
 
@@ -97,6 +110,14 @@ class GazePredictionGRU(ModelBase):
         self.predicted_gazemaps = None          # filled by predict(): probs for xentropy, raw maps for l2
         self.predicted_gazemaps_logit = None
         self.loss = None
+        # The reference's placeholders (gaze_rnn.py:114-129), read by name by callers that build their own feed_dict
+        # (extract_map.py:221-227: model.c3d_input, model.frame_images, model.gt_gazemap).  There is no graph to feed:
+        # they are inert descriptors (name / shape / dtype) so such code fails at its session.run with a message that
+        # names predict(), not with an AttributeError on the model.
+        B, T = self.batch_size, self.n_lstm_steps
+        self.frame_images = Placeholder('frame_images', (B, T, self.image_height, self.image_width, 3))
+        self.c3d_input = Placeholder('c3d_input', (B, T, 1024, 7, 7))
+        self.gt_gazemap = Placeholder('gt_gazemap', (B, T, self.gazemap_height, self.gazemap_width))
 
     @staticmethod
     def create_gazeprediction_network(frame_images, c3d_input, dropout_keep_prob=1.0, net=None, model=None):
@@ -167,9 +188,18 @@ class GazePredictionGRU(ModelBase):
         self.reducer = rdist.GradBucketReducer(dist, self.session.device) if dist is not None else None
 
     def _train_op(self, logits, probs, labels_dev):
-        self.engine.backward(logits, probs, labels_dev, 'l2' if self.config.loss_type == 'l2' else 'xentropy')
+        loss_type = 'l2' if self.config.loss_type == 'l2' else 'xentropy'
+        self.engine.backward(logits, probs, labels_dev, loss_type)
+        if self._status_or_recover():             # the BPTT launch timed out (NaN gradients): redo the step's forward
+            z, p = self.engine.forward(self._last_input, **self._last_forward_kw)[:2]      # and backward on the new engine
+            self.engine.backward(z, p, labels_dev, loss_type)
+            self._status_or_recover(final=True)
         if self.reducer is not None:
-            self.reducer.reduce(self.engine.flat_grads)       # in place, fp32, mean over ranks
+            buckets = getattr(self.engine, 'grad_buckets', None)
+            if callable(buckets):
+                self.reducer.reduce_buckets(buckets())        # in completion order, the first before the BPTT has ended
+            else:
+                self.reducer.reduce(self.engine.flat_grads)   # in place, fp32, mean over ranks
             self.reducer.finish()
         step_kw = {}
         if self.config.optimization_method != 'adam':
@@ -186,6 +216,11 @@ class GazePredictionGRU(ModelBase):
     def current_learning_rate(self):
         return self.learning_rate_at(self.current_step)
 
+    @property
+    def global_step(self):
+        """The reference's ``global_step`` variable (gaze_rnn.py:104; read by extract_map.py / the trainers): an int here."""
+        return self._global_step
+
     # ------------------------------------------------------------------ execution
     def predict(self, c3d, frames=None, train=False):
         """Replacement for ``session.run(predicted_gazemaps, feed_dict)`` (gaze_rnn.py:603-611):
@@ -198,9 +233,35 @@ class GazePredictionGRU(ModelBase):
         want_probs = self.config.loss_type in ('xentropy', 'KLD')
         kw = {'train': True} if (train and self._has_dropout()) else {}
         logits, probs = self.engine.forward(x, want_probs=want_probs, **kw)[:2]
+        if self._status_or_recover():             # the engine was replaced: compute this batch again with it
+            logits, probs = self.engine.forward(x, want_probs=want_probs, **kw)[:2]
+            self._status_or_recover(final=True)
+        self._last_input, self._last_forward_kw = x, dict(kw, want_probs=want_probs)
         self.predicted_gazemaps_logit = logits
         self.predicted_gazemaps = probs if want_probs else logits
         return self.predicted_gazemaps
+
+    def _status_or_recover(self, final=False):
+        """"A TF session either returns or raises" (gaze_rnn.py:603-611).  Engines with persistent launches report a lost
+        group member asynchronously (RGP_ETIMEOUT, NaN-poisoned outputs, include/rgp.h): wait for the stream, and on
+        that error let the model swap in an engine that does not depend on co-residency (_recover_from_timeout) --
+        returns True then, and the caller recomputes the batch.  Any other error, a model without a fallback, or
+        final=True: raises."""
+        status = getattr(self.engine, 'status', None)
+        if not callable(status):
+            return False
+        from .. import _lib
+        try:
+            status()
+            return False
+        except _lib.RgpError as err:
+            if final or err.code != _lib.RGP_ETIMEOUT or not self._recover_from_timeout():
+                raise
+            return True
+
+    def _recover_from_timeout(self):
+        """Models whose engine has a time-out-free variant override this (GazePredictionGRCN)."""
+        return False
 
     def _has_dropout(self):
         e = getattr(self.engine, 'net', self.engine)
@@ -260,47 +321,41 @@ class GazePredictionGRU(ModelBase):
         return step
 
     def generate(self, dataset, max_instances=50):
-        """gaze_rnn.py:568-650: same dictionary, same flattening of the time axis."""
-        GH, GW = self.gazemap_height, self.gazemap_width
-        pred_gazemap_list, gt_gazemap_list, fixationmap_list = [], [], []
-        images_list, filename_list, c3d_list = [], [], []
-        n_instances = len(dataset)
-        if max_instances is not None:
-            n_instances = min(n_instances, max_instances)
-        step_num = int(np.ceil(n_instances / float(self.batch_size)))
-        assert step_num > 0
-        for _ in range(step_num):
-            batch_images, batch_maps, batch_fixmaps, batch_c3d, batch_pupil, batch_filename = dataset.next_batch(self.batch_size)
-            batch_images = np.asarray(list(batch_images))
-            assert batch_images.dtype == np.float32
-            batch_c3d = np.reshape(batch_c3d, [self.batch_size, -1, 1024, 7, 7])
-            if self.config.loss_type == 'xentropy':
-                batch_maps = normalize_probability_map(batch_maps)
-            gazes = self.predict(batch_c3d, batch_images).cpu().numpy()
-            c3d_list.extend(batch_c3d)
-            pred_gazemap_list.extend(gazes)
-            gt_gazemap_list.extend(batch_maps)
-            fixationmap_list.extend(batch_fixmaps)
-            images_list.extend(np.concatenate(batch_images))
-            filename_list.extend(batch_filename)
-        status = getattr(self.engine, 'status', None)
-        if callable(status):
-            status()              # RGP_ETIMEOUT of a persistent ConvGRU launch (its maps are NaN) raises here
-        pred_gazemap_list = np.vstack(pred_gazemap_list).reshape([-1, GH, GW])
-        gt_gazemap_list = np.vstack(gt_gazemap_list).reshape([-1, GH, GW])
-        c3d_list = np.vstack(c3d_list).reshape([-1, 1024, 7, 7])
-        try:
-            fixationmap_list = np.vstack(fixationmap_list)
-        except Exception:
-            folded = []
-            for fixationmap in fixationmap_list:
-                for t in range(len(fixationmap)):
-                    folded.append(fixationmap[t])
-            fixationmap_list = folded
-            assert len(fixationmap_list) == len(pred_gazemap_list)
-        return {'pred_gazemap_list': pred_gazemap_list, 'gt_gazemap_list': gt_gazemap_list,
-                'images_list': images_list, 'fixationmap_list': fixationmap_list,
-                'clipname_list': filename_list, 'c3d_list': c3d_list}
+        """gaze_rnn.py:568-650: runs ceil(min(len(dataset), max_instances) / batch_size) batches through the network and
+        returns the reference's dictionary -- maps, ground truth and C3D features flattened over (clip, timestep);
+        ``fixationmap_list`` a dense array when the loader hands out dense maps, else a flat list of the per-frame
+        (sparse) maps; ``images_list`` per frame; ``clipname_list`` per clip."""
+        GH, GW, B = self.gazemap_height, self.gazemap_width, self.batch_size
+        n_instances = len(dataset) if max_instances is None else min(len(dataset), max_instances)
+        n_batches = -(-n_instances // B)
+        assert n_batches > 0
+        normalise_gt = self.config.loss_type == 'xentropy'
+        out = {'pred_gazemap_list': [], 'gt_gazemap_list': [], 'c3d_list': [], 'images_list': [], 'clipname_list': []}
+        fixations, dense_fixations = [], True
+        for _ in range(n_batches):
+            images, maps, fixmaps, c3d, _pupil, clipnames = dataset.next_batch(B)
+            images = np.asarray(list(images))
+            assert images.dtype == np.float32
+            c3d = np.reshape(c3d, [B, -1, 1024, 7, 7])
+            pred = self.predict(c3d, images).cpu().numpy()        # (predict() has waited for the engine's status)
+            out['pred_gazemap_list'].append(pred.reshape(-1, GH, GW))
+            out['gt_gazemap_list'].append(np.reshape(normalize_probability_map(maps) if normalise_gt else maps, (-1, GH, GW)))
+            out['c3d_list'].append(c3d.reshape(-1, 1024, 7, 7))
+            out['images_list'].extend(images.reshape((-1,) + images.shape[2:]))
+            out['clipname_list'].extend(clipnames)
+            for clip_fix in fixmaps:                              # one entry per clip: [T, H', W'] dense, or T sparse maps
+                dense_fixations = dense_fixations and isinstance(clip_fix, np.ndarray) and clip_fix.dtype != object
+                fixations.extend(clip_fix[t] for t in range(len(clip_fix)))
+        for key in ('pred_gazemap_list', 'gt_gazemap_list', 'c3d_list'):
+            out[key] = np.concatenate(out[key])
+        if dense_fixations:
+            try:
+                fixations = np.stack(fixations)
+            except ValueError:                                    # frames of different sizes: stays a list
+                pass
+        assert len(fixations) == len(out['pred_gazemap_list'])
+        out['fixationmap_list'] = fixations
+        return out
 
     def evaluate(self, pred_gazemap_list, gt_gazemap_list, fixationmap_list, images_list, **_ignored):
         """gaze_rnn.py:653-674.  Extra keys of generate()'s dictionary are accepted and ignored

@@ -85,3 +85,57 @@ def test_l2_loss_type_returns_raw_maps_and_lr_schedule(gpu, tmp_path):
     bad = syn.grcn_params(93, 5)
     with pytest.raises(AssertionError):
         model.load_state_dict(bad)                                      # T=5 BN layers into a T=3 model (9-Q1)
+
+
+def test_model_recovers_from_a_lost_persistent_launch(gpu, tmp_path):
+    """"a TF session either returns or raises" (gaze_rnn.py:603-611).  A persistent ConvGRU launch
+    that loses a group member (fault injection: rgp_grcn_inject_fault) NaN-poisons its maps and raises RGP_ETIMEOUT
+    asynchronously; the model class catches it at the end of predict() / after the backward, swaps in an engine that runs
+    the recurrence per timestep (RGP_GRCN_PER_STEP: a new plan object, same process, weights and Adam slots carried
+    over), recomputes the batch and carries on -- the caller sees finite maps equal to the per-step plan's."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    model, ds = make_model(gpu, tmp_path, T=3, B=4, dtype='bf16')
+    w = syn.grcn_params(97, 3, gru_std=0.05, random_bn=True)
+    model.load_state_dict(w)
+    _, _, _, c3d, _, _ = syn.SyntheticDataSet(12, 3, seed=5).next_batch(4)
+    assert not model.engine.per_step
+    good = model.predict(c3d).cpu().numpy()
+    model.engine.inject_fault('seq')
+    got = model.predict(c3d).cpu().numpy()                       # ~1 s: the time-out, then the recomputation
+    assert model.engine.per_step and model.config.convgru_per_step
+    assert np.isfinite(got).all()
+    ref = GrcnEngine(4, 3, dtype='bf16', device=gpu, per_step=True)
+    ref.set_weights(w)
+    x = torch.tensor(c3d.reshape(4, 3, 1024, 7, 7), device=gpu)
+    assert np.array_equal(got, ref.forward(x)[1].cpu().numpy())   # exactly the per-step plan's maps
+    assert np.abs(got - good).max() < 2e-2 * good.max()           # and the persistent plan's, to bf16 summation order
+    again = model.predict(c3d).cpu().numpy()                      # the model stays on the fallback, no second time-out
+    assert np.array_equal(again, got)
+
+    # training: the BPTT launch times out after one good step (Adam slots exist and must move to the new engine)
+    model2, _ = make_model(gpu, tmp_path / 'b', T=3, B=4, dtype='bf16')
+    model2.load_state_dict(w)
+    model2.config.use_flip_batch = False
+    twin, _ = make_model(gpu, tmp_path / 'c', T=3, B=4, dtype='bf16')
+    twin.load_state_dict(w)
+    twin.config.use_flip_batch = False
+    for m in (model2, twin):
+        m.single_step(train_mode=True, dataset=syn.SyntheticDataSet(12, 3, seed=6))
+    model2.engine.inject_fault('bptt')
+    data_a, data_b = syn.SyntheticDataSet(12, 3, seed=7), syn.SyntheticDataSet(12, 3, seed=7)
+    assert model2.single_step(train_mode=True, dataset=data_a) == 2
+    assert twin.single_step(train_mode=True, dataset=data_b) == 2
+    assert model2.engine.per_step and not twin.engine.per_step
+    a, b = model2.state_dict(), twin.state_dict()
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        # same two Adam steps up to the summation order of the two BPTT implementations: parameters moved by ~ +-lr
+        assert np.abs(a[k] - b[k]).max() <= 4.5 * model2.initial_learning_rate, k      # (noise-level gradients flip sign: 2 lr per step)
+    assert abs(float(model2.grad_norm.item()) - float(twin.grad_norm.item())) < 5e-2 * float(twin.grad_norm.item())
+
+
+def test_reference_placeholder_names_exist(gpu, tmp_path):
+    """extract_map.py:221-227 reads model.c3d_input / frame_images / gt_gazemap / global_step by name."""
+    model, _ = make_model(gpu, tmp_path)
+    assert model.c3d_input.shape == (2, 3, 1024, 7, 7) and model.frame_images.shape == (2, 3, 98, 98, 3)
+    assert model.gt_gazemap.get_shape() == (2, 3, 49, 49) and model.global_step == 0 and 'predict' in repr(model.c3d_input)
