@@ -196,6 +196,8 @@ def kernel_source_hashes():
 # sources that define a kernel's code and launch geometry (prefix of the name rgp_c3d_layer_kernel_name returns)
 KERNEL_SOURCES = {
     'conv_patch_bf16_kernel': ('conv_patch.hip.h', 'rgp_conv_patch.hip', 'rgp_c3d.hip', 'rgp_c3d_plan.h', 'rgp_host.h'),
+    'conv_patch_slab_bf16_kernel': ('conv_patch_slab.hip.h', 'conv_patch.hip.h', 'rgp_conv_patch.hip', 'rgp_c3d.hip', 'rgp_c3d_plan.h',
+                                    'rgp_host.h'),
     'conv_patch14_bf16_kernel': ('conv_patch14.hip.h', 'rgp_conv_patch.hip', 'rgp_c3d.hip', 'rgp_c3d_plan.h', 'rgp_host.h'),
 }
 

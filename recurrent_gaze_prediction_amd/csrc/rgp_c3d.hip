@@ -318,7 +318,8 @@ const char* rgp_c3d_layer_kernel_name(const rgp_c3d_t* c, int i, int n_windows) 
   if (bf && i == 0) {
     snprintf(buf, sizeof(buf), "conv1a_pool_bf16_kernel<%s>", c->save ? "act0,argmax" : "fused");
   } else if (bf && c->use_patch() && i >= 1 && i <= 3 && (i == 1 || c->L[i].chunk_major == 64)) {
-    snprintf(buf, sizeof(buf), "conv_patch_bf16_kernel<%d,%d,%d,%d,pool%d>", l.cin, l.cout, l.H, l.D, P);
+    snprintf(buf, sizeof(buf), "conv_patch%s_bf16_kernel<%d,%d,%d,%d,pool%d>", i == 1 && c->conv2a_slab() ? "_slab" : "", l.cin, l.cout,
+             l.H, l.D, P);
   } else if (bf && c->use_patch() && (i == 4 || i == 5) && c->L[i].chunk_major == 64) {
     snprintf(buf, sizeof(buf), "conv_patch14_bf16_kernel<%d,pool%d>", l.cin, P);
   } else if (bf && c->use_patch() && (i == 6 || i == 7) && c->L[i].chunk_major == 64) {

@@ -2,6 +2,7 @@
 // their input gradients, bf16.  Spec: /root/reference/C3D/.../c3d_prototxt/feature_extration.prototxt:67-240.
 #include "rgp_c3d_plan.h"
 #include "conv_patch.hip.h"
+#include "conv_patch_slab.hip.h"
 #include "conv_patch14.hip.h"
 #include "conv_patch7.hip.h"
 
@@ -24,6 +25,28 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
   auto kern = conv_patch_bf16_kernel<CIN, NOUT, HW, DEPTH, POOL, ARGMAX>;
+  RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
+  kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+// conv2a + pool2 on the plane-slab variant (conv_patch_slab.hip.h)
+template <bool ARGMAX>
+static int run_conv2a_slab(rgp_c3d* c, int n, hipStream_t s) {
+  using Cfg = PatchSlabCfg<64, 128, 56, 16, true>;
+  ConvPatchParams p;
+  p.in = (const bf16_t*)(c->ws + c->act_off[1]);
+  p.wp = (const bf16_t*)(c->ws + c->L[1].w_off);
+  p.bias = c->bias[1];
+  p.out = (bf16_t*)(c->ws + c->act_off[2]);
+  p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[1].argmax_off) : nullptr;
+  p.mask = nullptr;
+  p.n_windows = n;
+  p.ablate = dev_knob("RGP_CP_ABLATE", 0);
+  int n_cu = 0;
+  RGP_TRY(device_cu_count(&n_cu));
+  auto kern = conv_patch_slab_bf16_kernel<64, 128, 56, 16, true, ARGMAX>;
   RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
   kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
@@ -77,6 +100,7 @@ int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   if (layer == 7) return run_conv_patch7<1>(c, layer, n, s);
   if (layer == 4) return run_conv_patch14<256, false, false>(c, layer, n, s);
   if (layer == 5) return c->save ? run_conv_patch14<512, true, true>(c, layer, n, s) : run_conv_patch14<512, true, false>(c, layer, n, s);
+  if (layer == 1 && c->conv2a_slab()) return c->save ? run_conv2a_slab<true>(c, n, s) : run_conv2a_slab<false>(c, n, s);
   if (layer == 1) return c->save ? run_conv_patch<64, 128, 56, 16, true, true>(c, layer, n, s) : run_conv_patch<64, 128, 56, 16, true, false>(c, layer, n, s);
   if (layer == 2) return run_conv_patch<128, 256, 28, 8, false, false>(c, layer, n, s);
   if (layer == 3) return c->save ? run_conv_patch<256, 256, 28, 8, true, true>(c, layer, n, s) : run_conv_patch<256, 256, 28, 8, true, false>(c, layer, n, s);
