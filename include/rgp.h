@@ -71,9 +71,17 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
  *  RGP_GRCN_SAVE_FOR_BACKWARD  training plan (gates, states and operand images kept for rgp_grcn_backward);
  *  RGP_GRCN_PER_STEP           run the ConvGRU recurrence and its BPTT as per-timestep launches even where the
  *                              persistent kernels apply (bf16, 128 state channels, <= 64 clips): the library's second
- *                              implementation of the recurrence, always used by f32 plans. */
+ *                              implementation of the recurrence, always used by f32 plans;
+ *  RGP_GRCN_UNFOLDED_HEAD      inference plans run the saliency head (gaze_grcn.py:326-361) as ONE GEMM: the three
+ *                              transposed convolutions and out_W have no bias or non-linearity between them and are
+ *                              folded, exactly, into a 19x19 stride-6 filter on BN(h_t) when the weights are set.  With
+ *                              this flag the plan runs the three stages instead (deconv1, deconv2, deconv3 . out_W), as
+ *                              every training plan does (its filter gradients need the intermediate maps): the library's
+ *                              second implementation of the head; the buffers "d1" / "d2" of rgp_grcn_read_buffer exist
+ *                              only then. */
 #define RGP_GRCN_SAVE_FOR_BACKWARD 1
 #define RGP_GRCN_PER_STEP 2
+#define RGP_GRCN_UNFOLDED_HEAD 4
 /* The persistent ConvGRU kernels (one launch for all T steps, forward and BPTT) need all their workgroups resident
  * together: keep ONE of them in flight per device.  Launches issued through this library from one process are
  * serialised against each other automatically (any stream, any plan, any host thread: the wait for the previous

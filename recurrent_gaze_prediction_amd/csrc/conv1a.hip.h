@@ -51,7 +51,9 @@ struct Conv1aParams {
   const bf16_t* wp;     // [64][128]
   const float* bias;    // [64]
   bf16_t* out;          // [n][18][58][58][64] (halo-padded input of conv2a)
-  unsigned char* argmax;  // optional [n][16][56][56][64]: dy*2+dx of the first maximum of each pool1 window
+  unsigned char* argmax;  // optional [n][16][56][56][64]: dy*2+dx of the first maximum of each pool1 window, + 4 where the
+                          // pooled output stored beside it is zero (ReLU off: no gradient passes; conv1a_wgrad.hip.h then
+                          // need not read the activation back for its gate)
   int n_windows;
 };
 
@@ -282,7 +284,12 @@ static __global__ __launch_bounds__(256, 2) void conv1a_pool_bf16_kernel(const C
         }
       }
       dpk[j] = pk(v[0], v[1]);
-      if constexpr (ARGMAX) *(unsigned short*)(arow + (xg * 8 + 2 * j) * 64 + o_lane) = (unsigned short)codes;
+      if constexpr (ARGMAX) {
+        // the gate is taken from the bf16 value as stored (what every other consumer of the activation sees)
+        if ((dpk[j] & 0x7fffu) == 0) codes |= 4u;
+        if ((dpk[j] & 0x7fff0000u) == 0) codes |= 4u << 8;
+        *(unsigned short*)(arow + (xg * 8 + 2 * j) * 64 + o_lane) = (unsigned short)codes;
+      }
     }
     // the lane pair (2c, 2c+1) holds channels 4c .. 4c+3 of the 4 pixels: each trades one dword per pixel pair with its
     // partner (DPP quad_perm [1,0,3,2]) and stores 8 bytes of ONE pixel -- half the store instructions of the 4-byte

@@ -9,9 +9,11 @@
 // (3.7 ms): both only move zeros.  This kernel never materialises dY:
 //
 //  * jobs = (window, plane z, 2 pooled rows), dealt to the XCDs in contiguous ranges like the forward kernel;
-//    per job the 3 x 6 x 116-pixel input patch (16.3 KiB) and the 112 windows x 64 channels of dP (gated by
-//    y > 0 on the way in) and arg-max codes are fetched once with 16-byte loads into registers while the previous
-//    job computes, and parked in LDS (double-buffered, one barrier per job);
+//    per job the 3 x 6 x 116-pixel input patch (16.3 KiB) and the 112 windows x 64 channels of dP and arg-max codes
+//    are fetched once with 16-byte loads into registers while the previous job computes, and parked in LDS
+//    (double-buffered, one barrier per job).  dP is gated on the way in by bit 2 of the code, which the forward sets
+//    where the pooled output it stored is zero (conv1a.hip.h): round 3 read the 6.4 MB-per-window activation back for
+//    that (y > 0), 36 % of this kernel's bytes -- it is bound by its HBM reads (matrix pipe 27 % busy);
 //  * MFMA v_mfma_f32_16x16x32_bf16 with M = packed filter index (tap*4 + c: 27 taps x 4 = 108 -> 128),
 //    N = output channel, reduction = 32 conv rows = 8 pooling windows x (dy, dx):
 //      - A (X^T) fragments come straight out of the patch with the transposing LDS read ds_read_b64_tr_b16: a
@@ -32,7 +34,7 @@ struct Conv1aWgradParams {
   const bf16_t* in;            // act0 [n][18][114][116][4]
   const bf16_t* dyp;           // pooled gradient [n][16][56][56][64]
   const unsigned char* argmax; // [n][16][56][56][64]: dy*2+dx of the window's first maximum
-  const bf16_t* y;             // act1 [n][18][58][58][64]: pooled forward output (gate y > 0)
+  const bf16_t* y;             // act1 [n][18][58][58][64]: pooled forward output (not read: the gate y > 0 is bit 2 of the code)
   float* dw;                   // DHWIO [27][3][64] fp32, accumulated
   float* db;                   // [64] fp32, accumulated
   int n_windows;
@@ -83,15 +85,7 @@ static __global__ __launch_bounds__(512) void conv1a_wgrad_bf16_kernel(const Con
     const int kz = row / W1_PROWS, ry = row - kz * W1_PROWS;
     p_off[u] = ((kz * C1_HP + ry) * C1_WP) * 4 + c * 8;
   }
-  int y_off[W1_NGL];                                       // gradient item c = tid + 512 u: window c>>3, channels 8(c&7)..
-#pragma unroll
-  for (int u = 0; u < W1_NGL; ++u) {
-    int c = tid + 512 * u;
-    if (c >= W1_GCHUNKS) c = W1_GCHUNKS - 1;
-    const int wj = c >> 3, yl = wj / C1_PO, xo = wj - yl * C1_PO;
-    y_off[u] = ((yl * C1_OUT_P) + xo) * 64 + (c & 7) * 8;
-  }
-  struct Fetched { u32x4 px[W1_NPL]; u32x4 g[W1_NGL]; u32x4 yv[W1_NGL]; uint2 am[W1_NGL]; };
+  struct Fetched { u32x4 px[W1_NPL]; u32x4 g[W1_NGL]; uint2 am[W1_NGL]; };
   auto fetch = [&](long long j, Fetched& f) {
     const int yh = (int)(j % W1_YH);
     const int z = (int)((j / W1_YH) % C1_D);
@@ -100,14 +94,12 @@ static __global__ __launch_bounds__(512) void conv1a_wgrad_bf16_kernel(const Con
 #pragma unroll
     for (int u = 0; u < W1_NPL; ++u) f.px[u] = *(const u32x4*)(src + p_off[u]);
     const long long w0 = ((n * C1_D + z) * C1_PO + yh * W1_JROWS) * (long long)C1_PO;      // first window of the job
-    const bf16_t* ysrc = p.y + (((n * (C1_D + 2) + z + 1) * C1_OUT_P + yh * W1_JROWS + 1) * (long long)C1_OUT_P + 1) * 64;
 #pragma unroll
     for (int u = 0; u < W1_NGL; ++u) {
       int c = tid + 512 * u;
       if (c >= W1_GCHUNKS) c = W1_GCHUNKS - 1;
       f.g[u] = *(const u32x4*)(p.dyp + w0 * 64 + (long long)c * 8);
       f.am[u] = *(const uint2*)(p.argmax + w0 * 64 + (long long)c * 8);
-      f.yv[u] = *(const u32x4*)(ysrc + y_off[u]);
     }
   };
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -121,10 +113,10 @@ static __global__ __launch_bounds__(512) void conv1a_wgrad_bf16_kernel(const Con
       if (c < W1_GCHUNKS) {
         u32x4 g = f.g[u];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // gate by y > 0 (bf16: sign clear and non-zero)
-          const unsigned yy = f.yv[u][k];
-          const unsigned keep_lo = ((yy & 0x7fffu) != 0 && !(yy & 0x8000u)) ? 0xffffu : 0u;
-          const unsigned keep_hi = ((yy & 0x7fff0000u) != 0 && !(yy & 0x80000000u)) ? 0xffff0000u : 0u;
+        for (int k = 0; k < 4; ++k) {                       // gate by y > 0: bit 2 of the channel's code (conv1a.hip.h)
+          const unsigned cw = k < 2 ? f.am[u].x : f.am[u].y;
+          const unsigned keep_lo = (cw >> (16 * (k & 1))) & 4u ? 0u : 0xffffu;
+          const unsigned keep_hi = (cw >> (16 * (k & 1) + 8)) & 4u ? 0u : 0xffff0000u;
           g[k] &= keep_lo | keep_hi;
           bsum[2 * k] += __uint_as_float(g[k] << 16);
           bsum[2 * k + 1] += __uint_as_float(g[k] & 0xffff0000u);

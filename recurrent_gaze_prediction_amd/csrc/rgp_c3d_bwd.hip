@@ -91,6 +91,85 @@ __global__ __launch_bounds__(256) void unpool_kernel(const T* __restrict__ dyp, 
   block_colsum(bsum, cg, rl, RL, C, db);
 }
 
+// The same for the bf16 2x2x2-pooled layers (conv2a, conv3b, conv4b), laid out for the WRITE stream, which is 8x the reads
+// (3.3 GB per 256 windows for conv2a): a store instruction of a wave covers ONE contiguous kilobyte of dYpre -- lanes =
+// (window of a run of WPI windows adjacent in x, dx, 8-channel group), so the 64/LPP positions 2 xo + dx ... of an image
+// row lie side by side -- instead of four 256-byte pieces of four windows.  The two dx lanes of a window load the same
+// pooled gradient / code / activation (one request).  grid = (blocks, windows of the batch): no 64-bit division.
+// (round 4: the three launches 1.7 -> see DESIGN.md ms per 256 windows)
+template <int C>
+__global__ __launch_bounds__(256) void unpool8_rows_kernel(const bf16_t* __restrict__ dyp, const unsigned char* __restrict__ amax,
+                                                           const bf16_t* __restrict__ y, const int* __restrict__ y_tab,
+                                                           long long y_img_stride, bf16_t* __restrict__ dypre,
+                                                           const int* __restrict__ win_tab, long long dypre_stride, int PR,
+                                                           int q_dz, int q_dy, float* __restrict__ db) {
+  constexpr int LPP = C / 8;                       // lanes per position: 16 / 32 / 64
+  constexpr int DXL = LPP == 64 ? 1 : 2;           // dx values across lanes (C = 512: dx is looped)
+  constexpr int WPI = 64 / (LPP * DXL);            // windows per wave iteration: 2 / 1 / 1
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = lane % LPP, dxl = (lane / LPP) % DXL, wsub = lane / (LPP * DXL);
+  const long long img = blockIdx.y;
+  const bf16_t* gimg = dyp + img * (long long)PR * C;
+  const unsigned char* aimg = amax + img * (long long)PR * C;
+  const bf16_t* yimg = y + img * y_img_stride;
+  bf16_t* oimg = dypre + img * dypre_stride;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int pr0 = (blockIdx.x * 4 + wave) * WPI; pr0 < PR; pr0 += gridDim.x * 4 * WPI) {
+    const int pr = pr0 + wsub;
+    float g[8];
+    mp_load8(gimg + (long long)pr * C + cg * 8, g);
+    float yv[8];
+    mp_load8(yimg + y_tab[pr] + cg * 8, yv);
+    const uint2 cw = *reinterpret_cast<const uint2*>(aimg + (long long)pr * C + cg * 8);
+    unsigned code[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      code[k] = ((k < 4 ? cw.x : cw.y) >> (8 * (k & 3))) & 0xffu;
+      g[k] = yv[k] > 0.f ? g[k] : 0.f;
+      if (DXL == 1 || dxl == 0) bsum[k] += g[k];
+    }
+    bf16_t* base = oimg + win_tab[pr] + cg * 8;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dxi = 0; dxi < 2 / DXL; ++dxi) {
+          const int dx = DXL == 2 ? dxl : dxi;
+          const unsigned q = (unsigned)(dz * 4 + dy * 2 + dx);
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = code[k] == q ? g[k] : 0.f;
+          store8<bf16_t>(base + dz * q_dz + dy * q_dy + dx * C, v, 8);
+        }
+  }
+  // bias gradient: per-block reduction, one atomic per channel and block
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = bsum[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int t = c / 8; t < 256; t += LPP) a += red[t * 8 + (c & 7)];
+    if (a != 0.f) atomicAdd(db + c, a);
+  }
+}
+
+template <int C>
+static int launch_unpool8_rows(const bf16_t* dyp, const unsigned char* amax, const bf16_t* y, const int* y_tab, long long y_img_stride,
+                               bf16_t* dypre, const int* win_tab, long long dypre_stride, int PR, int q_dz, int q_dy, int n,
+                               float* db, hipStream_t s) {
+  constexpr int WPI = C == 128 ? 2 : 1;
+  const int per_block = 4 * WPI;
+  int bx = (PR + per_block - 1) / per_block;
+  // enough blocks to fill the chip about eight times over, each wave a few iterations
+  const int want = std::max(1, 8192 / std::max(n, 1));
+  bx = std::max(1, std::min(bx, want));
+  unpool8_rows_kernel<C><<<dim3(bx, n), 256, 0, s>>>(dyp, amax, y, y_tab, y_img_stride, dypre, win_tab, dypre_stride, PR, q_dz, q_dy, db);
+  RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
 // Bias gradient of an un-pooled layer: column sums over the interior rows of dYpre.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ buf, const int* __restrict__ tab, long long img_stride,
@@ -235,7 +314,21 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       const long long rows = (long long)n * PR;
       // bf16 conv1a consumes the pooled gradient directly (conv1a_wgrad.hip.h): its 6.4 MB-per-window dY image is
       // only built on demand by rgp_c3d_read_grad_image
-      if (!(i == 1 && sizeof(T) == 2)) unpool_kernel<T><<<blocks_for(rows, 256 / (ll.cout / 8) * 8), 256, 0, s>>>(
+      const bool rows8 = sizeof(T) == 2 && ll.pd == 2 && ll.ph == 2 && (ll.cout == 128 || ll.cout == 256 || ll.cout == 512) &&
+                         (ll.cout != 128 || (ll.H / 2) % 2 == 0) && dev_knob("RGP_UNPOOL_ROWS", 1);
+      if (rows8) {
+        const int Hp = ll.H + 2;
+        const int q_dz = Hp * Hp * ll.cout, q_dy = Hp * ll.cout;
+        const bf16_t* dyp = (const bf16_t*)(ws + c->dyp_off);
+        const unsigned char* am = (const unsigned char*)(ws + lo.argmax_off);
+        const bf16_t* yf = (const bf16_t*)(ws + c->act_off[i]);
+        const int* ytab = (const int*)(ws + c->unpad_off[i - 1]);
+        bf16_t* out = (bf16_t*)(ws + lo.dypre_off);
+        const int* wtab = (const int*)(ws + lo.win_tab_off);
+        if (ll.cout == 128) RGP_TRY(launch_unpool8_rows<128>(dyp, am, yf, ytab, c->act_stride[i], out, wtab, lo.dypre_stride, PR, q_dz, q_dy, n, grads + lo.grad_b, s));
+        else if (ll.cout == 256) RGP_TRY(launch_unpool8_rows<256>(dyp, am, yf, ytab, c->act_stride[i], out, wtab, lo.dypre_stride, PR, q_dz, q_dy, n, grads + lo.grad_b, s));
+        else RGP_TRY(launch_unpool8_rows<512>(dyp, am, yf, ytab, c->act_stride[i], out, wtab, lo.dypre_stride, PR, q_dz, q_dy, n, grads + lo.grad_b, s));
+      } else if (!(i == 1 && sizeof(T) == 2)) unpool_kernel<T><<<blocks_for(rows, 256 / (ll.cout / 8) * 8), 256, 0, s>>>(
           (const T*)(ws + c->dyp_off), (const unsigned char*)(ws + lo.argmax_off), (const T*)(ws + c->act_off[i]),
           (const int*)(ws + c->unpad_off[i - 1]), c->act_stride[i], (T*)(ws + lo.dypre_off), (const int*)(ws + lo.win_tab_off),
           (const int*)(ws + lo.q_off_off), lo.dypre_stride, PR, ll.cout, ll.pd * ll.ph * ll.ph, rows, grads + lo.grad_b);

@@ -100,7 +100,7 @@ int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   if (layer == 7) return run_conv_patch7<1>(c, layer, n, s);
   if (layer == 4) return run_conv_patch14<256, false, false>(c, layer, n, s);
   if (layer == 5) return c->save ? run_conv_patch14<512, true, true>(c, layer, n, s) : run_conv_patch14<512, true, false>(c, layer, n, s);
-  if (layer == 1 && c->conv2a_slab()) return c->save ? run_conv2a_slab<true>(c, n, s) : run_conv2a_slab<false>(c, n, s);
+  if (layer == 1 && c->conv2a_slab()) return run_conv2a_slab<false>(c, n, s);
   if (layer == 1) return c->save ? run_conv_patch<64, 128, 56, 16, true, true>(c, layer, n, s) : run_conv_patch<64, 128, 56, 16, true, false>(c, layer, n, s);
   if (layer == 2) return run_conv_patch<128, 256, 28, 8, false, false>(c, layer, n, s);
   if (layer == 3) return c->save ? run_conv_patch<256, 256, 28, 8, true, true>(c, layer, n, s) : run_conv_patch<256, 256, 28, 8, true, false>(c, layer, n, s);

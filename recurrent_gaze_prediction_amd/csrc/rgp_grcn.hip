@@ -7,6 +7,7 @@
 #include "rgp_grcn_plan.h"
 #include "convgru_seq.hip.h"
 #include "head_logits.hip.h"
+#include "head_fold.hip.h"
 
 using namespace rgp;
 
@@ -221,6 +222,12 @@ int seq_impl(rgp_grcn* g, hipStream_t s) {
 
 template <typename T>
 int head_impl(rgp_grcn* g, float* logits, hipStream_t s) {
+  if (g->fold_head) {                                          // head_fold.hip.h: logits = BN(h) x Wd + out_b, one launch
+    IgemmParams p = make_params(g->hfold, g->ws + g->hbn.off, g->ws, g->F);
+    EpiParams e = make_epi(g->hfold, logits, g->ws);
+    e.bias = (const float*)(g->ws + g->hf_bias.off);
+    return launch_igemm<T, 1, 1, EpiStore<float, true, false>>(p, e, s);
+  }
   for (const ConvDesc& d : g->d1) {
     IgemmParams p = make_params(d, g->ws + g->hbn.off, g->ws, g->F);
     EpiParams e = make_epi(d, g->ws + g->D1.off, g->ws);
@@ -292,7 +299,8 @@ extern "C" {
 int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int dim_state, int dtype,
                     int flags) {
   RGP_REQUIRE(plan, "rgp_grcn_create: null out pointer");
-  RGP_REQUIRE((flags & ~(RGP_GRCN_SAVE_FOR_BACKWARD | RGP_GRCN_PER_STEP)) == 0, "rgp_grcn_create: unknown flags 0x%x", flags);
+  RGP_REQUIRE((flags & ~(RGP_GRCN_SAVE_FOR_BACKWARD | RGP_GRCN_PER_STEP | RGP_GRCN_UNFOLDED_HEAD)) == 0,
+              "rgp_grcn_create: unknown flags 0x%x", flags);
   const int save_for_backward = flags & RGP_GRCN_SAVE_FOR_BACKWARD;
   RGP_REQUIRE(batch > 0 && n_steps > 0, "rgp_grcn_create: batch=%d n_steps=%d", batch, n_steps);
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_grcn_create: dtype %d", dtype);
@@ -304,6 +312,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   rgp_grcn* g = new rgp_grcn();
   g->B = batch; g->T = n_steps; g->P = dim_proj; g->S = dim_state; g->dtype = dtype; g->save = save_for_backward;
   g->F = batch * n_steps;
+  g->fold_head = !save_for_backward && !(flags & RGP_GRCN_UNFOLDED_HEAD);
   const int P = g->P, S = g->S, F = g->F, es = esize(dtype);
   bool ok = true;
 
@@ -362,9 +371,21 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
     ok &= build_k_schedule(d, tapoff, fidx, 22 * 32, dtype);
     d.s_tap = 16LL * 704; d.s_n = 704; d.s_c = 1;           // gtoep [u][n][x'*32 + c]
   }
+  if (g->fold_head) {
+    // the folded head (head_fold.hip.h): one GEMM row per frame, K = the 49 pixels x S channels of the padded BN(h) image,
+    // N = the 2401 pixels of the logit map
+    ConvDesc& d = g->hfold;
+    d.Mw = 1; d.N = 2401; d.in_img_stride = 81LL * S; d.out_img_stride = 2401;
+    d.in_tab = {0}; d.out_tab = {0};
+    std::vector<int> tapoff, fidx;
+    for (int m = 0; m < 7; ++m) for (int n = 0; n < 7; ++n) { tapoff.push_back(((m + 1) * 9 + n + 1) * S); fidx.push_back(m * 7 + n); }
+    ok &= build_k_schedule(d, tapoff, fidx, S, dtype);
+    d.s_tap = (long long)S * 2401; d.s_n = 1; d.s_c = 2401;   // Wd [tap][s][pixel]
+  }
   if (!ok) { delete g; return set_err(RGP_EINVAL, "rgp_grcn_create: unsupported channel geometry P=%d S=%d", P, S); }
 
   Arena a;
+  if (g->fold_head) g->hfold.reserve(a, dtype);
   for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3, &g->d3t}) d->reserve(a, dtype);
   for (ConvDesc& d : g->d1) d.reserve(a, dtype);
   for (ConvDesc& d : g->d2) d.reserve(a, dtype);
@@ -398,8 +419,15 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->hp = take(a, (size_t)batch * 81 * S * es);
   g->rhp = take(a, (size_t)batch * 81 * S * es);
   g->hbn = take(a, (size_t)F * 81 * S * es);
-  g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
-  g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es + 4096);   // slack: the Toeplitz filter-gradient rows of pixel block 3 read past the last row
+  if (g->fold_head) {                                      // no intermediate maps: the fold's fp32 work areas instead
+    g->hf_h = take(a, (size_t)HF_HP * HF_HP * 64 * 4);
+    g->hf_k = take(a, (size_t)HF_KP * HF_KP * S * 4);
+    g->hf_w = take(a, (size_t)49 * S * 2401 * 4);
+    g->hf_bias = take(a, (size_t)g->hfold.n_pad() * 4);
+  } else {
+    g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
+    g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es + 4096);   // slack: the Toeplitz filter-gradient rows of pixel block 3 read past the last row
+  }
   g->gfold = take(a, 50 * 32 * 4);
   g->gtoep = take(a, (size_t)7 * 16 * 704 * 4);
   g->bias16 = take(a, 16 * 4);
@@ -463,6 +491,7 @@ int rgp_grcn_bind_workspace(rgp_grcn_t* g, void* workspace, size_t bytes, rgp_st
   // epilogues only ever write interiors.
   RGP_HIP(hipMemsetAsync(g->ws, 0, g->ws_bytes, s));
   for (ConvDesc* d : {&g->proj, &g->proj_rows, &g->xconv, &g->gzr, &g->gc, &g->d3, &g->d3t}) RGP_TRY(upload_desc(*d, g->ws, s));
+  if (g->fold_head) RGP_TRY(upload_desc(g->hfold, g->ws, s));
   for (ConvDesc& d : g->d1) RGP_TRY(upload_desc(d, g->ws, s));
   for (ConvDesc& d : g->d2) RGP_TRY(upload_desc(d, g->ws, s));
   for (ConvDesc& d : g->d1_pack) RGP_TRY(upload_desc(d, g->ws, s));
@@ -576,6 +605,7 @@ static bool find_view(const rgp_grcn* g, const char* name, BufView& v) {
   if (n == "c3d_embedded") v = {g->E.off, g->o_pad9_P, 49, P, 81LL * P, g->F, false};
   else if (n == "xpre") v = {g->xpre.off, g->o_lin49_3S, 49, 3 * S, 49LL * 3 * S, g->F, true};
   else if (n == "bn") v = {g->hbn.off, g->o_pad9_S, 49, S, 81LL * S, g->F, false};
+  else if ((n == "d1" || n == "d2") && g->fold_head) return false;      // the folded head has no intermediate maps
   else if (n == "d1") v = {g->D1.off, g->o_pad27, 529, 64, 27LL * 27 * 64, g->F, false};
   else if (n == "d2") v = {g->D2.off, g->o_pad55, 2401, 32, 55LL * 55 * 32, g->F, false};
   else if (n == "u") v = {g->uall.off, g->o_lin49_S, 49, S, 49LL * S, (long long)g->T * g->B, true};

@@ -161,9 +161,12 @@ class GrcnEngine(object):
     """gaze_grcn graph (models/gaze_grcn.py:173-376) at fixed (B, T, P, S, dtype)."""
 
     def __init__(self, batch, n_steps, dim_proj=512, dim_state=128, dtype='bf16', save_for_backward=False,
-                 device='cuda:0', per_step=False):
+                 device='cuda:0', per_step=False, unfolded_head=False):
         """per_step=True: the recurrence (and its BPTT) as per-timestep launches even where the persistent
-        kernels apply (RGP_GRCN_PER_STEP): the library's second implementation, used for cross-checks."""
+        kernels apply (RGP_GRCN_PER_STEP): the library's second implementation, used for cross-checks.
+        unfolded_head=True: an inference plan that runs the three transposed convolutions one by one
+        (RGP_GRCN_UNFOLDED_HEAD) instead of their exact fold into one GEMM (csrc/head_fold.hip.h); training plans
+        always do."""
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.B, self.T, self.P, self.S = int(batch), int(n_steps), int(dim_proj), int(dim_state)
@@ -172,7 +175,8 @@ class GrcnEngine(object):
         self.torch_dtype = torch.bfloat16 if _lib.DTYPES[dtype] == _lib.RGP_BF16 else torch.float32
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            flags = (_lib.RGP_GRCN_SAVE_FOR_BACKWARD if save_for_backward else 0) | (_lib.RGP_GRCN_PER_STEP if per_step else 0)
+            flags = (_lib.RGP_GRCN_SAVE_FOR_BACKWARD if save_for_backward else 0) | (_lib.RGP_GRCN_PER_STEP if per_step else 0) | \
+                (_lib.RGP_GRCN_UNFOLDED_HEAD if unfolded_head else 0)
             _lib.check(self.lib.rgp_grcn_create(ctypes.byref(self._h), self.B, self.T, self.P, self.S,
                                                 _lib.DTYPES[dtype], flags))
             nbytes = self.lib.rgp_grcn_workspace_bytes(self._h)
@@ -320,6 +324,10 @@ class GrcnEngine(object):
         """Test hook (rgp_grcn_inject_fault): kind 'seq' / 'bptt' -- the next persistent launch loses a member."""
         _lib.check(self.lib.rgp_grcn_inject_fault(self._h, {'seq': _lib.RGP_FAULT_SEQ_LOST_MEMBER,
                                                             'bptt': _lib.RGP_FAULT_BPTT_LOST_MEMBER}[kind]))
+
+    def read_buffer_elems(self, name):
+        """fp32 elements read_buffer(name) returns; 0 = this plan has no such intermediate."""
+        return int(self.lib.rgp_grcn_buffer_elems(self._h, name.encode()))
 
     def read_buffer(self, name):
         n = self.lib.rgp_grcn_buffer_elems(self._h, name.encode())

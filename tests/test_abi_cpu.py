@@ -40,8 +40,15 @@ def test_plan_creation_and_validation_are_host_only():
     ws_bf16 = lib.rgp_grcn_workspace_bytes(h)
     assert ws_bf16 > 64 * 16 * 49 * 1024 * 2                    # at least the transposed input
     assert lib.rgp_grcn_buffer_elems(h, b'rcn_outputs') == 64 * 16 * 49 * 128
-    assert lib.rgp_grcn_buffer_elems(h, b'd2') == 64 * 16 * 2401 * 32
+    assert lib.rgp_grcn_buffer_elems(h, b'd2') == 0             # inference plans fold the head into one GEMM: no d1 / d2
     assert lib.rgp_grcn_buffer_elems(h, b'nope') == 0
+    hu = ctypes.c_void_p()
+    assert lib.rgp_grcn_create(ctypes.byref(hu), 64, 16, 512, 128, _lib.RGP_BF16, _lib.RGP_GRCN_UNFOLDED_HEAD) == 0
+    assert lib.rgp_grcn_buffer_elems(hu, b'd2') == 64 * 16 * 2401 * 32
+    # the folded plan trades the two intermediate maps (293 MB at 1024 frames) for a 30 MB filter + its 60 MB fp32 source
+    assert lib.rgp_grcn_workspace_bytes(hu) - ws_bf16 > 150e6
+    lib.rgp_grcn_destroy(hu)
+    assert lib.rgp_grcn_create(ctypes.byref(hu), 1, 1, 512, 128, _lib.RGP_BF16, 8) != 0 and b'flags' in lib.rgp_last_error()
     # forward before a workspace is bound is refused with RGP_EWORKSPACE (-3), not a crash
     assert lib.rgp_convgru_seq_fwd(h, None) == -3
     assert b'workspace' in lib.rgp_last_error()
@@ -81,7 +88,10 @@ def test_c3d_kernel_names_and_flags_host_only():
         return out
     d = names(0, 1024)
     assert d[0].startswith('conv1a_pool_bf16_kernel')
-    assert d[1] == 'conv_patch_bf16_kernel<64,128,56,16,pool8>' and d[2] == 'conv_patch_bf16_kernel<128,256,28,8,pool1>'
+    # conv2a's inference forward runs the plane-slab variant of the patch kernel (csrc/conv_patch_slab.hip.h); a training
+    # plan (arg-max codes recorded) the row-wise one
+    assert d[1] == 'conv_patch_slab_bf16_kernel<64,128,56,16,pool8>' and d[2] == 'conv_patch_bf16_kernel<128,256,28,8,pool1>'
+    assert names(_lib.RGP_C3D_SAVE_FOR_BACKWARD, 256, max_windows=256)[1] == 'conv_patch_bf16_kernel<64,128,56,16,pool8>'
     assert d[3] == 'conv_patch_bf16_kernel<256,256,28,8,pool8>'
     assert d[4] == 'conv_patch14_bf16_kernel<256,pool1>' and d[5] == 'conv_patch14_bf16_kernel<512,pool8>'
     assert d[6] == 'conv_patch7_bf16_kernel<image>' and d[7] == 'conv_patch7_bf16_kernel<rows>'
@@ -91,13 +101,13 @@ def test_c3d_kernel_names_and_flags_host_only():
     t = names(_lib.RGP_C3D_KERNELS_IGEMM | _lib.RGP_C3D_KERNELS_TILE128, 1024)
     assert all(x.startswith('igemm_kernel<128x128,bf16') for x in t[1:])
     small = names(0, 2, max_windows=2)
-    assert small[1].startswith('conv_patch_bf16_kernel') and small[6] == 'conv_patch7_bf16_kernel<image>'
+    assert small[1].startswith('conv_patch_slab_bf16_kernel') and small[6] == 'conv_patch7_bf16_kernel<image>'
     f32 = names(0, 1024, dtype=_lib.RGP_F32)
     assert f32[0] == 'igemm_kernel<128x64,f32,pool4>' and f32[3] == 'igemm_stagger_kernel<256x128,f32,pool8>'
     h = ctypes.c_void_p()
     assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, 8) == -1                      # unknown flag
     assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, _lib.RGP_C3D_KERNELS_TILE128) == -1
-    assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, 4) == -1           # unknown flag
+    assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, 8) == -1           # unknown flag
     assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, _lib.RGP_GRCN_PER_STEP) == 0
     lib.rgp_grcn_destroy(h)
 

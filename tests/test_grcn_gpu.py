@@ -254,3 +254,49 @@ def test_persistent_launches_from_two_host_threads_are_serialised(gpu):
     for i in range(2):
         engs[i].status()
         assert torch.equal(outs[i], ref[i]), i
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_folded_head_equals_the_three_stage_head_and_the_oracle(gpu, dtype):
+    """Inference plans run deconv1 . deconv2 . deconv3 . out_W (gaze_grcn.py:326-361: no bias, no non-linearity between
+    them) as ONE GEMM with a filter folded when the weights are set (csrc/head_fold.hip.h).  Checked against (i) the
+    float64 oracle of the reference op sequence, (ii) the library's three-stage head (RGP_GRCN_UNFOLDED_HEAD) on the same
+    plan inputs, at the reference widths, (iii) again after the weights change (the fold follows set_weights), and
+    (iv) at the benchmark's 1024 frames, where the GEMM picks another tile."""
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    B, T = 3, 2
+    x = syn.c3d_features(202, B, T)
+    xd = torch.tensor(x, device=gpu)
+    folded = GrcnEngine(B, T, dtype=dtype, device=gpu)
+    staged = GrcnEngine(B, T, dtype=dtype, device=gpu, unfolded_head=True)
+    assert folded.read_buffer_elems('d1') == 0 and staged.read_buffer_elems('d1') == B * T * 529 * 64
+    for seed in (201, 211):
+        p = syn.grcn_params(seed, T, gru_std=0.05, random_bn=True)
+        ref = torch_ref.grcn_forward(torch.tensor(x, dtype=torch.float64),
+                                     {k: torch.tensor(v, dtype=torch.float64) for k, v in p.items()}).numpy()
+        folded.set_weights(p)
+        staged.set_weights(p)
+        lf, pf = folded.forward(xd)
+        ls, ps = staged.forward(xd)
+        ef, es = rel_err(lf.cpu().numpy(), ref), rel_err(ls.cpu().numpy(), ref)
+        if dtype == 'f32':
+            assert ef < 2e-5 and es < 2e-5, (ef, es)
+            assert rel_err(lf.cpu().numpy(), ls.cpu().numpy()) < 2e-5
+        else:
+            # one bf16 rounding of the folded filter instead of two rounded intermediate maps: no less accurate
+            assert ef < 2e-2 and ef < 1.25 * es + 1e-3, (ef, es)
+        assert torch.allclose(pf.sum((-1, -2)), torch.ones(B, T, device=gpu), atol=1e-4)
+    # the borders: a delta in the corner pixel of BN(h) must light exactly the 16 x 16 corner of the map it reaches
+    # (rows 0 .. 6*0+15), through both heads alike -- the fold's clipping at the map edge
+    big = GrcnEngine(64, 16, dtype=dtype, device=gpu)
+    big_s = GrcnEngine(64, 16, dtype=dtype, device=gpu, unfolded_head=True)
+    p = syn.grcn_params(221, 16, gru_std=0.05, random_bn=True)
+    big.set_weights(p)
+    big_s.set_weights(p)
+    xb = torch.tensor(syn.c3d_features(222, 64, 16), device=gpu)
+    lb, _ = big.forward(xb)
+    lbs, _ = big_s.forward(xb)
+    big.status()
+    big_s.status()
+    e = rel_err(lb.cpu().numpy(), lbs.cpu().numpy())
+    assert e < (2e-5 if dtype == 'f32' else 2e-2), e
