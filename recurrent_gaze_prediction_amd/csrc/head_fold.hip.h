@@ -9,7 +9,7 @@
 //   d2[2i+a', 2j+b', c] += d1[i,j,k] F2[a',b',c,k]                            (5 x 5, stride 2, VALID: 23 -> 49)
 //   d1[3m+a", 3n+b", k] += y[m,n,s] F1[a",b",k,s]                             (5 x 5, stride 3, VALID:  7 -> 23)
 //
-//   => logit[y,x] = out_b + sum_{i,j,k} d1[i,j,k] H[y-2i, x-2j, k]            H[p,q,k] = sum_{a'-a+3 = p, b'-b+3 = q, c} G[a,b,c] F2[a',b',c,k]
+//   => logit[y,x] = out_b + sum_{i,j,k} d1[i,j,k] H[y-2i, x-2j, k]            H[p,q,k] = sum_{a'+a-3 = p, b'+b-3 = q, c} G[a,b,c] F2[a',b',c,k]
 //                                                                             p, q in [-3, 7]:  11 x 11 x 64
 //   => logit[y,x] = out_b + sum_{m,n,s} y[m,n,s] K[y-6m, x-6n, s]             K[r,t,s] = sum_{2a"+p = r, 2b"+q = t, k} F1[a",b",k,s] H[p,q,k]
 //                                                                             r, t in [-3, 15]: 19 x 19 x 128
@@ -38,10 +38,10 @@ static __global__ void head_fold_h_kernel(const float* __restrict__ g, const flo
   const int k = i % 64, q = (i / 64) % HF_HP - 3, p = i / (64 * HF_HP) - 3;
   float s = 0.f;
   for (int a = 0; a < 7; ++a) {
-    const int a1 = p + a - 3;
+    const int a1 = p - a + 3;
     if (a1 < 0 || a1 > 4) continue;
     for (int b = 0; b < 7; ++b) {
-      const int b1 = q + b - 3;
+      const int b1 = q - b + 3;
       if (b1 < 0 || b1 > 4) continue;
       const float* gp = g + (a * 7 + b) * 32;
       const float* fp = f2 + ((long long)(a1 * 5 + b1) * 32) * 64 + k;

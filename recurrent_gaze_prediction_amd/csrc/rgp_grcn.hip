@@ -267,6 +267,17 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
                                                                           (float*)(ws + g->bias16.off));
   RGP_HIP(hipGetLastError());
   RGP_TRY(pk.add(g->d3t, (const float*)(ws + g->gtoep.off), 16, 0));
+  if (g->fold_head) {
+    // the whole head as one matrix (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1 -> dense [tap][s][pixel]
+    float* hf = (float*)(ws + g->hf_h.off);
+    float* kf = (float*)(ws + g->hf_k.off);
+    float* wd = (float*)(ws + g->hf_w.off);
+    head_fold_h_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(gf, w->up_weight2, hf);
+    head_fold_k_kernel<<<(HF_KP * HF_KP * S + 255) / 256, 256, 0, s>>>(hf, w->up_weight1, kf, S);
+    head_fold_expand_kernel<<<4096, 256, 0, s>>>(kf, w->out_b, wd, (float*)(ws + g->hf_bias.off), S, g->hfold.n_pad());
+    RGP_HIP(hipGetLastError());
+    RGP_TRY(pk.add(g->hfold, wd, 2401, 0));
+  }
   RGP_TRY(pk.flush());
   g->bn_gamma = w->bn_gamma;
   g->bn_beta = w->bn_beta;

@@ -104,7 +104,7 @@ def test_model_recovers_from_a_lost_persistent_launch(gpu, tmp_path):
     got = model.predict(c3d).cpu().numpy()                       # ~1 s: the time-out, then the recomputation
     assert model.engine.per_step and model.config.convgru_per_step
     assert np.isfinite(got).all()
-    ref = GrcnEngine(4, 3, dtype='bf16', device=gpu, per_step=True)
+    ref = GrcnEngine(4, 3, dtype='bf16', device=gpu, per_step=True, save_for_backward=True)   # (the model's plan is a training plan)
     ref.set_weights(w)
     x = torch.tensor(c3d.reshape(4, 3, 1024, 7, 7), device=gpu)
     assert np.array_equal(got, ref.forward(x)[1].cpu().numpy())   # exactly the per-step plan's maps
