@@ -22,8 +22,19 @@
 // dividing by the UNFOLDED 432.79 MFLOP per frame.  Fewer roundings than the staged bf16 pipeline (the
 // intermediates are never rounded to bf16; the folded filter is, once).
 //
-// Training plans keep the three stages (their filter gradients need d1 and d2), and so does an inference plan created with
-// RGP_GRCN_UNFOLDED_HEAD: the library's second implementation of the head, which the tests compare this one with.
+// Training plans fold too (second half of round 4).  The backward never needs the dense matrix, only K and the patches
+// Pm[(f,m,n)][(r,t)] = dz[f, 6m+r, 6n+t] of the logit gradient (19 x 19 = 361 taps, padded to 384, zero outside the map):
+//
+//   dK[(r,t), s]   = sum_{(f,m,n)} Pm[(f,m,n), (r,t)] y[f,m,n,s]              one wgrad_kernel launch (rows = the 7 x 7 positions)
+//   dy[(f,m,n), s] = sum_{(r,t)}   Pm[(f,m,n), (r,t)] K[(r,t), s]             one GEMM, K = 384, N = S
+//   dF1[a",b",k,s] = sum_{p,q} H[p,q,k] dK[2a"+p, 2b"+q, s]        dH[p,q,k] = sum_{a",b",s} F1[a",b",k,s] dK[2a"+p, 2b"+q, s]
+//   dF2[a',b',c,k] = sum_{a,b} G[a,b,c] dH[a'+a-3, b'+b-3, k]      dG[a,b,c] = sum_{a',b',k} F2[a',b',c,k] dH[a'+a-3, b'+b-3, k]
+//   dF3 = dG (x) out_W,  d out_W = <dG, F3>   (head_unfold_grads_kernel, as before)
+//
+// (the chain rule through the fold, checked against autograd to 1e-12 before it was written down here): 7 small launches
+// and two GEMMs of 1.3 / 4.3 GFLOP at 280 frames replace three filter-gradient launches, two input-gradient GEMMs, the
+// Toeplitz filter gradient and the intermediate maps d1 / d2 / dd1 / dd2.  RGP_GRCN_UNFOLDED_HEAD keeps the three stages, forward
+// and backward: the library's second implementation of the head, which the tests compare this one with.
 #pragma once
 #include "igemm.hip.h"
 
@@ -84,6 +95,109 @@ static __global__ void head_fold_expand_kernel(const float* __restrict__ kf, con
     wd[i] = (r >= 0 && r < HF_KP && t >= 0 && t < HF_KP) ? kf[((long long)r * HF_KP + t) * S + s] : 0.f;
     if (i < n_bias) bias[i] = out_b[0];
   }
+}
+
+// The packed GEMM filter straight from K, in the operand type: dst[col][(m*7+n)*S + s] = K[y-6m, x-6n, s], rows col >= 2401
+// zero; bias[col] = out_b.  (Training plans re-fold after every optimizer step: 30 MB written, no fp32 intermediate.)
+template <typename T>
+static __global__ void head_fold_pack_kernel(const float* __restrict__ kf, const float* __restrict__ out_b, T* __restrict__ dst,
+                                             float* __restrict__ bias, int S, int n_pad) {
+  const int SG = S / 8;
+  const long long total = (long long)n_pad * 49 * SG;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int sg = (int)(i % SG);
+    const int tap = (int)((i / SG) % 49);
+    const int col = (int)(i / (49LL * SG));
+    const int y = col / 49, x = col - y * 49, m = tap / 7, n = tap - m * 7;
+    const int r = y - 6 * m + 3, t = x - 6 * n + 3;
+    float v[8];
+    if (col < 2401 && r >= 0 && r < HF_KP && t >= 0 && t < HF_KP) {
+      const float* src = kf + ((long long)r * HF_KP + t) * S + sg * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
+    store8<T>(dst + (long long)col * (49 * S) + tap * S + sg * 8, v, 8);
+    if (i < n_pad) bias[i] = out_b[0];
+  }
+}
+
+constexpr int HF_PK = 384;                  // 361 taps of K padded to a multiple of the K-chunk (64 bf16 / 32 fp32 elements)
+
+// Pm[(f, m, n)][(r+3)*19 + t+3] = dz[f, 6m+r, 6n+t] for r, t in [-3, 15] inside the map, else 0; columns 361 .. 383 zero
+template <typename T>
+static __global__ void head_fold_patches_kernel(const float* __restrict__ dz, T* __restrict__ pm, long long rows) {
+  const long long total = rows * HF_PK;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % HF_PK);
+    const long long row = i / HF_PK;
+    const int pos = (int)(row % 49);
+    const long long f = row / 49;
+    float v = 0.f;
+    if (k < HF_KP * HF_KP) {
+      const int y = 6 * (pos / 7) + k / HF_KP - 3, x = 6 * (pos % 7) + k % HF_KP - 3;
+      if (y >= 0 && y < 49 && x >= 0 && x < 49) v = dz[f * 2401 + y * 49 + x];
+    }
+    pm[i] = Elem<T>::to(v);
+  }
+}
+
+// dF1[a,b,k,s] = sum_{p,q} H[p,q,k] dK[2a+p, 2b+q, s]          (dk: [HF_PK][S], row (r+3)*19 + t+3)
+static __global__ void head_unfold_f1_kernel(const float* __restrict__ dk, const float* __restrict__ h, float* __restrict__ df1, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 25 * 64 * S) return;
+  const int s = i % S, k = (i / S) % 64, ab = i / (S * 64), a = ab / 5, b = ab % 5;
+  float acc = 0.f;
+  for (int p = 0; p < HF_HP; ++p)
+    for (int q = 0; q < HF_HP; ++q)
+      acc += h[(p * HF_HP + q) * 64 + k] * dk[((long long)(2 * a + p) * HF_KP + 2 * b + q) * S + s];
+  df1[i] = acc;
+}
+
+// dH[p,q,k] = sum_{a,b,s} F1[a,b,k,s] dK[2a+p, 2b+q, s]        (one block per (p,q), thread = k x 4 slices of s)
+static __global__ __launch_bounds__(256) void head_unfold_h_kernel(const float* __restrict__ dk, const float* __restrict__ f1,
+                                                                  float* __restrict__ dh, int S) {
+  __shared__ float red[256];
+  const int pq = blockIdx.x, p = pq / HF_HP, q = pq % HF_HP;
+  const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int ab = 0; ab < 25; ++ab) {
+    const int a = ab / 5, b = ab % 5;
+    const float* dkr = dk + ((long long)(2 * a + p) * HF_KP + 2 * b + q) * S;
+    const float* fr = f1 + ((long long)ab * 64 + k) * S;
+    for (int s = sl; s < S; s += 4) acc += fr[s] * dkr[s];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) dh[pq * 64 + k] = red[k] + red[64 + k] + red[128 + k] + red[192 + k];
+}
+
+// dF2[a',b',c,k] = sum_{a,b} G[a,b,c] dH[a'+a-3, b'+b-3, k]    (dh index p+3 = a'+a)
+static __global__ void head_unfold_f2_kernel(const float* __restrict__ dh, const float* __restrict__ g, float* __restrict__ df2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 25 * 32 * 64) return;
+  const int k = i % 64, c = (i / 64) % 32, ab = i / (64 * 32), a1 = ab / 5, b1 = ab % 5;
+  float acc = 0.f;
+  for (int a = 0; a < 7; ++a)
+    for (int b = 0; b < 7; ++b) acc += g[(a * 7 + b) * 32 + c] * dh[((a1 + a) * HF_HP + b1 + b) * 64 + k];
+  df2[i] = acc;
+}
+
+// dGp[6-a, 6-b, c] = dG[a,b,c] = sum_{a',b',k} F2[a',b',c,k] dH[a'+a-3, b'+b-3, k]     (flipped: what head_unfold_grads_kernel reads)
+static __global__ void head_unfold_g_kernel(const float* __restrict__ dh, const float* __restrict__ f2, float* __restrict__ dgp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 49 * 32) return;
+  const int c = i % 32, tap = i / 32, a = tap / 7, b = tap % 7;
+  float acc = 0.f;
+  for (int ab = 0; ab < 25; ++ab) {
+    const int a1 = ab / 5, b1 = ab % 5;
+    const float* fr = f2 + ((long long)ab * 32 + c) * 64;
+    const float* dr = dh + ((a1 + a) * HF_HP + b1 + b) * 64;
+    for (int k = 0; k < 64; ++k) acc += fr[k] * dr[k];
+  }
+  dgp[((6 - a) * 7 + (6 - b)) * 32 + c] = acc;
 }
 
 }  // namespace rgp

@@ -280,7 +280,7 @@ int rgp_cascade_create_ex(rgp_cascade_t** plan, int batch, int n_steps, int imag
   g->B = batch; g->T = n_steps; g->F = batch * n_steps; g->dtype = dtype; g->image_hw = image_hw;
   g->save = save_for_backward != 0;
   int rc = rgp_grcn_create(&g->bottom, batch, n_steps, 512, 256, dtype,
-                           g->save ? RGP_GRCN_SAVE_FOR_BACKWARD : RGP_GRCN_UNFOLDED_HEAD);   // (the bottom plan's own head is never run: no fold)
+                           (g->save ? RGP_GRCN_SAVE_FOR_BACKWARD : 0) | RGP_GRCN_UNFOLDED_HEAD);   // (the bottom plan's own head is never run: no fold)
   if (rc == RGP_OK) rc = rgp_shallownet_create(&g->shallow, g->F, image_hw, dtype);
   if (rc != RGP_OK) { rgp_cascade_destroy(g); return rc; }
   const int es = esize(dtype), F = g->F;

@@ -268,15 +268,14 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_HIP(hipGetLastError());
   RGP_TRY(pk.add(g->d3t, (const float*)(ws + g->gtoep.off), 16, 0));
   if (g->fold_head) {
-    // the whole head as one matrix (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1 -> dense [tap][s][pixel]
+    // the whole head as one matrix (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1 -> the packed GEMM filter
     float* hf = (float*)(ws + g->hf_h.off);
     float* kf = (float*)(ws + g->hf_k.off);
-    float* wd = (float*)(ws + g->hf_w.off);
     head_fold_h_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(gf, w->up_weight2, hf);
     head_fold_k_kernel<<<(HF_KP * HF_KP * S + 255) / 256, 256, 0, s>>>(hf, w->up_weight1, kf, S);
-    head_fold_expand_kernel<<<4096, 256, 0, s>>>(kf, w->out_b, wd, (float*)(ws + g->hf_bias.off), S, g->hfold.n_pad());
+    head_fold_pack_kernel<T><<<2048, 256, 0, s>>>(kf, w->out_b, (T*)(ws + g->hfold.w_off), (float*)(ws + g->hf_bias.off), S,
+                                                  g->hfold.n_pad());
     RGP_HIP(hipGetLastError());
-    RGP_TRY(pk.add(g->hfold, wd, 2401, 0));
   }
   RGP_TRY(pk.flush());
   g->bn_gamma = w->bn_gamma;
@@ -323,7 +322,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   rgp_grcn* g = new rgp_grcn();
   g->B = batch; g->T = n_steps; g->P = dim_proj; g->S = dim_state; g->dtype = dtype; g->save = save_for_backward;
   g->F = batch * n_steps;
-  g->fold_head = !save_for_backward && !(flags & RGP_GRCN_UNFOLDED_HEAD);
+  g->fold_head = !(flags & RGP_GRCN_UNFOLDED_HEAD);
   const int P = g->P, S = g->S, F = g->F, es = esize(dtype);
   bool ok = true;
 
@@ -391,7 +390,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
     std::vector<int> tapoff, fidx;
     for (int m = 0; m < 7; ++m) for (int n = 0; n < 7; ++n) { tapoff.push_back(((m + 1) * 9 + n + 1) * S); fidx.push_back(m * 7 + n); }
     ok &= build_k_schedule(d, tapoff, fidx, S, dtype);
-    d.s_tap = (long long)S * 2401; d.s_n = 1; d.s_c = 2401;   // Wd [tap][s][pixel]
+    d.s_tap = 0; d.s_n = 0; d.s_c = 0;                          // (packed by head_fold_pack_kernel, not by pack_filter)
   }
   if (!ok) { delete g; return set_err(RGP_EINVAL, "rgp_grcn_create: unsupported channel geometry P=%d S=%d", P, S); }
 
@@ -430,10 +429,9 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   g->hp = take(a, (size_t)batch * 81 * S * es);
   g->rhp = take(a, (size_t)batch * 81 * S * es);
   g->hbn = take(a, (size_t)F * 81 * S * es);
-  if (g->fold_head) {                                      // no intermediate maps: the fold's fp32 work areas instead
+  if (g->fold_head) {                                      // no intermediate maps: the fold's small fp32 work areas instead
     g->hf_h = take(a, (size_t)HF_HP * HF_HP * 64 * 4);
     g->hf_k = take(a, (size_t)HF_KP * HF_KP * S * 4);
-    g->hf_w = take(a, (size_t)49 * S * 2401 * 4);
     g->hf_bias = take(a, (size_t)g->hfold.n_pad() * 4);
   } else {
     g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);

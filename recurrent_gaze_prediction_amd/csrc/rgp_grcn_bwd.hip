@@ -16,12 +16,15 @@
 #include "rgp_grcn_plan.h"
 #include "wgrad_launch.h"
 #include "convgru_bptt.hip.h"
+#include "head_fold.hip.h"
 
 using namespace rgp;
 
 struct GrcnBwd {
   ConvDesc b_d2, b_d1, b_c, b_zr, b_x;     // dgrad convolutions
   ConvDesc b_px;                           // projection input gradient: d rows = dE x W^T
+  ConvDesc b_hf;                           // folded head (head_fold.hip.h): dy = Pm x K, rows = (frame, 7x7 position), K = 384
+  Buf pm, dkf, dhf;                        // its patches [F*49][384] T, dK [384][S] and dH [11,11,64] fp32
   // gather tables [ntaps][Mw] (element offsets, -1 = zero) + offsets in the workspace
   std::vector<int> t_y, t_pad3S, t_pad2S, koff_c;
   size_t o_y = 0, o_pad3S = 0, o_pad2S = 0, o_koff_c = 0;
@@ -147,6 +150,36 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // 1. d loss / d logits, d out_b
   dlogits_kernel<<<F, 256, 0, s>>>(loss_l2 ? logits : probs, labels, Fp(b->dz), Fp(b->frame_sum), 2401, 1.0f / (float)F, loss_l2);
   sum_kernel<<<1, 256, 0, s>>>(Fp(b->frame_sum), (float*)gr->out_b, F, 1.0f);
+  if (g->fold_head) {
+    // 2'-4'. the folded head (head_fold.hip.h): patches of dz -> dK (one wgrad launch: rows = the 7x7 positions, X = the
+    // patches, dY = the padded BN(h) image, as deconv1's filter gradient) -> chain rule through the fold -> dy = Pm x K
+    const long long tot = M * HF_PK;
+    head_fold_patches_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>(Fp(b->dz), Tp(b->pm), M);
+    RGP_HIP(hipGetLastError());
+    RGP_HIP(hipMemsetAsync(ws + b->dkf.off, 0, b->dkf.bytes, s));
+    {
+      WgradParams p = wg_params();
+      p.X = Tp(b->pm); p.dY = Tp(g->hbn); p.dW = Fp(b->dkf);
+      wgrad_grid(p, 1, 7, 7);
+      p.x_sx = HF_PK; p.x_sy = 7 * HF_PK; p.x_img_stride = 49LL * HF_PK;
+      p.y_sx = S; p.y_sy = 9 * S; p.y_org = 10 * S; p.y_img_stride = 81LL * S;
+      p.koff = I(b->o_koff_c); p.M = M; p.N = S; p.nk = HF_PK / Elem<T>::BKE; p.ldw = S; p.k_valid = HF_PK;
+      RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    }
+    const float* hf = (const float*)(ws + g->hf_h.off);
+    const float* gf = (const float*)(ws + g->gfold.off);
+    head_unfold_f1_kernel<<<(25 * 64 * S + 255) / 256, 256, 0, s>>>(Fp(b->dkf), hf, (float*)gr->up_weight1, S);
+    head_unfold_h_kernel<<<HF_HP * HF_HP, 256, 0, s>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhf), S);
+    head_unfold_f2_kernel<<<(25 * 32 * 64 + 255) / 256, 256, 0, s>>>(Fp(b->dhf), gf, (float*)gr->up_weight2);
+    head_unfold_g_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(Fp(b->dhf), b->w.up_weight2, Fp(b->dgp));
+    head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
+    RGP_HIP(hipGetLastError());
+    {
+      IgemmParams p = make_params(b->b_hf, Tp(b->pm), ws, F);
+      EpiParams e = make_epi(b->b_hf, Fp(b->dy), ws);
+      RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+    }
+  } else {
   // 2. folded 7x7 filter: wgrad -> dF3, d out_W ; dgrad -> dd2
   {
     const long long tot = (long long)F * 49 * 64;
@@ -203,6 +236,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     EpiParams e = make_epi(b->b_d1, Fp(b->dy), ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
   }
+  }  // !fold_head
   }  // !ext_dy
   // 5. per-timestep batch-norm
   const float inv = 1.0f / sqrtf(1.0f + 1e-3f);
@@ -338,6 +372,7 @@ int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_TRY(pk.add(b->b_x, w->gru_Wz, P, 0, 0, 1));
   RGP_TRY(pk.add(b->b_x, w->gru_Wr, P, 0, S, 1));
   RGP_TRY(pk.add(b->b_x, w->gru_W, P, 0, 2 * S, 1));
+  if (g->fold_head) RGP_TRY(pk.add(b->b_hf, (const float*)(ws + g->hf_k.off), S, 0));     // K of the folded head (set_weights_impl built it)
   RGP_TRY(pk.flush());
   // Gp[u,v,c] = G[6-u,6-v,c] in fp32 for the folded-filter dgrad (G itself is in g->gfold)
   // (49*32 elements; reuse the pack kernel with T=float semantics is overkill: tiny copy kernel)
@@ -403,8 +438,16 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
     ok &= build_k_schedule(d, {0}, {0}, P, dtype);
     d.s_tap = 0; d.s_n = 2LL * P; d.s_c = 1;
   }
+  {  // folded head: dy[(f,m,n), s] = sum_k Pm[(f,m,n), k] K[k, s]   (head_fold.hip.h; K [361][S] fp32, rows 361..383 zero)
+    ConvDesc& d = b->b_hf;
+    d.Mw = 49; d.N = S; d.in_img_stride = 49LL * HF_PK; d.out_img_stride = 49LL * S;
+    for (int pos = 0; pos < 49; ++pos) { d.in_tab.push_back(pos * HF_PK); d.out_tab.push_back(pos * S); }
+    ok &= build_k_schedule(d, {0}, {0}, HF_PK, dtype);
+    d.cin_src = HF_KP * HF_KP;
+    d.s_tap = 0; d.s_n = 1; d.s_c = S;
+  }
   if (!ok) return set_err(RGP_EINVAL, "rgp_grcn_create: backward K schedule failed");
-  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) d->reserve(a, dtype);
+  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px, &b->b_hf}) d->reserve(a, dtype);
 
   // ---- small tables
   for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x) {
@@ -421,8 +464,14 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   b->frame_sum = take(a, (size_t)F * 4);
   b->dgp = take(a, 50 * 32 * 4);
   b->gp = take(a, 50 * 32 * 4);
-  b->dd2 = take(a, (size_t)F * 2401 * 32 * es + 4096);
-  b->dd1 = take(a, (size_t)F * 529 * 64 * es + 4096);
+  if (g->fold_head) {
+    b->pm = take(a, (size_t)F * 49 * HF_PK * es);
+    b->dkf = take(a, (size_t)HF_PK * S * 4);
+    b->dhf = take(a, (size_t)HF_HP * HF_HP * 64 * 4);
+  } else {
+    b->dd2 = take(a, (size_t)F * 2401 * 32 * es + 4096);
+    b->dd1 = take(a, (size_t)F * 529 * 64 * es + 4096);
+  }
   b->dy = take(a, (size_t)F * 49 * S * 4);
   b->dh_head = take(a, st * T_);
   b->dh_carry = take(a, st);
@@ -439,8 +488,10 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
     b->xch_r = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
     b->bptt_cnt = take(a, (size_t)g->seq_groups * 2 * T_ * 4);
   }
-  b->dzb = take(a, ((size_t)F * 49 * 64 + 256) * es);
-  b->ptoep = take(a, (size_t)7 * 16 * 704 * 4);
+  if (!g->fold_head) {
+    b->dzb = take(a, ((size_t)F * 49 * 64 + 256) * es);
+    b->ptoep = take(a, (size_t)7 * 16 * 704 * 4);
+  }
   b->hp_all = take(a, (size_t)T_ * B * 81 * S * es);
   b->rhp_all = take(a, (size_t)T_ * B * 81 * S * es);
   b->sq_partial = take(a, SQ_BLOCKS * 4);
@@ -449,7 +500,7 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
 
 int grcn_bwd_upload(rgp_grcn* g, hipStream_t s) {
   GrcnBwd* b = g->bwd;
-  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px}) RGP_TRY(upload_desc(*d, g->ws, s));
+  for (ConvDesc* d : {&b->b_d2, &b->b_d1, &b->b_c, &b->b_zr, &b->b_x, &b->b_px, &b->b_hf}) RGP_TRY(upload_desc(*d, g->ws, s));
   auto up = [&](const std::vector<int>& t, size_t off) -> int {
     RGP_HIP(hipMemcpyAsync(g->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
     return RGP_OK;

@@ -30,11 +30,15 @@ def case(seed, B, T, P, S):
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('B,T,P,S', [(2, 3, 64, 64), (1, 2, 512, 128)])
 @pytest.mark.parametrize('loss_type', ['xentropy', 'l2'])
-def test_gradients_match_autograd(gpu, dtype, B, T, P, S, loss_type):
+@pytest.mark.parametrize('head', ['folded', 'three-stage'])
+def test_gradients_match_autograd(gpu, dtype, B, T, P, S, loss_type, head):
+    """Both implementations of the saliency head's backward -- the chain rule through the folded 19x19 filter
+    (csrc/head_fold.hip.h, the default) and the three transposed convolutions one by one (RGP_GRCN_UNFOLDED_HEAD) -- against
+    float64 autograd of the reference op sequence."""
     from recurrent_gaze_prediction_amd.engine import GrcnEngine
     p, x, g = case(101, B, T, P, S)
     _, _, ref = torch_ref.grcn_loss_and_grads(x, g, p, loss_type=loss_type)
-    eng = GrcnEngine(B, T, P, S, dtype=dtype, save_for_backward=True, device=gpu)
+    eng = GrcnEngine(B, T, P, S, dtype=dtype, save_for_backward=True, device=gpu, unfolded_head=head == 'three-stage')
     eng.set_weights(p)
     logits, probs = eng.forward(torch.tensor(x, device=gpu))
     grads = eng.backward(logits, probs, torch.tensor(g, device=gpu), loss_type)
@@ -48,15 +52,16 @@ def test_gradients_match_autograd(gpu, dtype, B, T, P, S, loss_type):
         assert e < TOL[dtype], '%s: rel err %.3e' % (k, e)
 
 
+@pytest.mark.parametrize('head', ['folded', 'three-stage'])
 @pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 3e-2)])
-def test_bptt_through_35_steps_matches_autograd(gpu, dtype, tol):
+def test_bptt_through_35_steps_matches_autograd(gpu, dtype, tol, head):
     """BASELINE config 4's clip length (the reference's older default, model_gru_rcn.py:188): B=2, T=35 at the
     reference widths against float64 autograd -- the error growth of bf16 operands through a 35-step backward."""
     from recurrent_gaze_prediction_amd.engine import GrcnEngine
     B, T, P, S = 2, 35, 512, 128
     p, x, g = case(211, B, T, P, S)
     _, _, ref = torch_ref.grcn_loss_and_grads(x, g, p, loss_type='xentropy')
-    eng = GrcnEngine(B, T, P, S, dtype=dtype, save_for_backward=True, device=gpu)
+    eng = GrcnEngine(B, T, P, S, dtype=dtype, save_for_backward=True, device=gpu, unfolded_head=head == 'three-stage')
     eng.set_weights(p)
     logits, probs = eng.forward(torch.tensor(x, device=gpu))
     grads = eng.backward(logits, probs, torch.tensor(g, device=gpu), 'xentropy')

@@ -55,7 +55,9 @@ def test_every_intermediate_against_oracle(gpu, dtype):
     p = syn.grcn_params(51, T, P, S, gru_std=0.05, random_bn=True)
     x = syn.c3d_features(52, B, T)
     ref_logits, it = grcn.forward(x, p, want_intermediates=True)
-    eng = GrcnEngine(B, T, P, S, dtype=dtype, save_for_backward=True, device=gpu)
+    # (unfolded_head: the plan that HAS the intermediate maps d1 / d2 -- the three-stage head; the folded one is checked against it
+    # and against the oracle in tests/test_grcn_gpu.py)
+    eng = GrcnEngine(B, T, P, S, dtype=dtype, save_for_backward=True, device=gpu, unfolded_head=True)
     eng.set_weights(p)
     logits, _ = eng.forward(torch.tensor(x, device=gpu))
     tol = TOL[dtype]
