@@ -16,11 +16,14 @@
 //
 // Exact, borders included: a VALID transposed convolution produces exactly the rows 0 .. 48 (2 * 22 + 4), so the zero
 // padding of the SAME 7 x 7 stage never meets a value the fold would have to drop, and the output is simply restricted to
-// 0 <= y, x < 49.  As a matrix: logits[f, (y,x)] = sum_{(m,n,s)} Y[f, (m,n,s)] Wd[(m,n,s), (y,x)], a 6272 x 2401 matrix with
-// 15 % non-zeros, run DENSE: 30.8 MFLOP per frame instead of the 164.6 of the three stages, no 27 x 27 x 64 / 55 x 55 x 32
-// intermediates (293 MB per 1024 frames written and read back), one launch instead of six.  All reported rates keep
-// dividing by the UNFOLDED 432.79 MFLOP per frame.  Fewer roundings than the staged bf16 pipeline (the
-// intermediates are never rounded to bf16; the folded filter is, once).
+// 0 <= y, x < 49.  The head is then ONE transposed convolution (19 x 19, stride 6, S -> 1 channels), run as GEMM + col2im:
+//   Z[(f,m,n), (r,t)] = sum_s y[f,m,n,s] K[(r,t), s]          igemm: M = frames x 49, K = S, N = 361 -> 384: 4.8 MFLOP per frame
+//   logit[f,y,x] = out_b + sum_{m,n} Z[(f,m,n), (y-6m, x-6n)]  head_col2im_kernel: <= 4 x 4 terms per pixel, fp32
+// instead of the 164.6 MFLOP of the three stages, with no 27 x 27 x 64 / 55 x 55 x 32 intermediates (293 MB per 1024 frames
+// written and read back): two launches instead of six.  (First form of this round: the dense 6272 x 2401 matrix, 30.8 MFLOP
+// per frame and a 30 MB filter -- 0.08 ms per 1024 frames, but 66 us at config 4's 280 frames: 190 tiles of 64 x 64 each
+// streaming K = 6272.)  All reported rates keep dividing by the UNFOLDED 432.79 MFLOP per frame.  Fewer roundings
+// than the staged bf16 pipeline (the intermediates are never rounded to bf16; the folded filter is, once).
 //
 // Training plans fold too (second half of round 4).  The backward never needs the dense matrix, only K and the patches
 // Pm[(f,m,n)][(r,t)] = dz[f, 6m+r, 6n+t] of the logit gradient (19 x 19 = 361 taps, padded to 384, zero outside the map):
@@ -41,6 +44,7 @@
 namespace rgp {
 
 constexpr int HF_HP = 11, HF_KP = 19;      // taps of H and K per axis
+constexpr int HF_PK = 384;                 // the 361 taps of K padded to a multiple of the K-chunk (64 bf16 / 32 fp32 elements)
 
 // H[(p+3)*11 + q+3][k] from G [7*7][32] (fold_head_filter_kernel) and weight2 [5,5,32,64] = (kh, kw, out, in)
 static __global__ void head_fold_h_kernel(const float* __restrict__ g, const float* __restrict__ f2, float* __restrict__ h) {
@@ -62,69 +66,47 @@ static __global__ void head_fold_h_kernel(const float* __restrict__ g, const flo
   h[i] = s;
 }
 
-// K[(r+3)*19 + t+3][s] from H and weight1 [5,5,64,S] = (kh, kw, out, in)
+// K[(r+3)*19 + t+3][s] += sum_{b,k} F1[a,b,k,s] H[r-2a, t-2b, k]: block = ((r,t), a), thread = s; kf zeroed by the caller
+// (a thread per (r,t,s) looping over all 25 x 64 terms took 57 us: 180 blocks of serial loads; this form 1805 blocks of 320)
 static __global__ void head_fold_k_kernel(const float* __restrict__ h, const float* __restrict__ f1, float* __restrict__ kf, int S) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= HF_KP * HF_KP * S) return;
-  const int s = i % S, t = (i / S) % HF_KP - 3, r = i / (S * HF_KP) - 3;
-  float acc = 0.f;
-  for (int a = 0; a < 5; ++a) {
-    const int p = r - 2 * a;
-    if (p < -3 || p > 7) continue;
+  const int rt = blockIdx.x, a = blockIdx.y;
+  const int r = rt / HF_KP - 3, t = rt % HF_KP - 3;
+  const int p = r - 2 * a;
+  if (p < -3 || p > 7) return;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    float acc = 0.f;
     for (int b = 0; b < 5; ++b) {
       const int q = t - 2 * b;
       if (q < -3 || q > 7) continue;
       const float* hp = h + ((p + 3) * HF_HP + q + 3) * 64;
       const float* fp = f1 + ((long long)(a * 5 + b) * 64) * S + s;
+#pragma unroll 8
       for (int k = 0; k < 64; ++k) acc += hp[k] * fp[(long long)k * S];
     }
+    atomicAdd(kf + (long long)rt * S + s, acc);
   }
-  kf[i] = acc;
 }
 
-// Wd[tap = m*7+n][s][col = y*49+x] = K[y-6m, x-6n, s] (0 outside its 19 x 19 taps);  bias[col] = out_b
-static __global__ void head_fold_expand_kernel(const float* __restrict__ kf, const float* __restrict__ out_b, float* __restrict__ wd,
-                                               float* __restrict__ bias, int S, int n_bias) {
-  const long long total = 49LL * S * 2401;
+// Forward, second half (col2im of the transposed convolution): the GEMM  Z[(f,m,n)][(r,t)] = sum_s y[f,m,n,s] K[(r,t),s]
+// (M = frames x 49, K = S, N = 384: 1/6 of the dense matrix's FLOPs, no 30 MB filter) leaves every product of a 7x7 position
+// with the 19x19 filter; a logit pixel gathers its <= 4 x 4 contributions:  logit[f,y,x] = out_b + sum_{m,n} Z[(f,m,n)][(y-6m, x-6n)]
+static __global__ __launch_bounds__(256) void head_col2im_kernel(const float* __restrict__ z, const float* __restrict__ out_b,
+                                                                float* __restrict__ logits, long long total) {
+  const float bias = out_b[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int col = (int)(i % 2401);
-    const int s = (int)((i / 2401) % S);
-    const int tap = (int)(i / (2401LL * S));
-    const int y = col / 49, x = col - y * 49, m = tap / 7, n = tap - m * 7;
-    const int r = y - 6 * m + 3, t = x - 6 * n + 3;
-    wd[i] = (r >= 0 && r < HF_KP && t >= 0 && t < HF_KP) ? kf[((long long)r * HF_KP + t) * S + s] : 0.f;
-    if (i < n_bias) bias[i] = out_b[0];
+    const int pix = (int)(i % 2401);
+    const long long f = i / 2401;
+    const int y = pix / 49, x = pix - y * 49;
+    // m with -3 <= y - 6m <= 15  <=>  (y - 15) / 6 <= m <= (y + 3) / 6
+    const int m0 = y > 15 ? (y - 10) / 6 : 0, m1 = min(6, (y + 3) / 6);      // ceil((y - 15) / 6) = (y - 10) / 6 for y >= 16
+    const int n0 = x > 15 ? (x - 10) / 6 : 0, n1 = min(6, (x + 3) / 6);
+    float acc = bias;
+    for (int m = m0; m <= m1; ++m)
+      for (int n = n0; n <= n1; ++n)
+        acc += z[((f * 49 + m * 7 + n) * HF_PK) + (y - 6 * m + 3) * HF_KP + (x - 6 * n + 3)];
+    logits[i] = acc;
   }
 }
-
-// The packed GEMM filter straight from K, in the operand type: dst[col][(m*7+n)*S + s] = K[y-6m, x-6n, s], rows col >= 2401
-// zero; bias[col] = out_b.  (Training plans re-fold after every optimizer step: 30 MB written, no fp32 intermediate.)
-template <typename T>
-static __global__ void head_fold_pack_kernel(const float* __restrict__ kf, const float* __restrict__ out_b, T* __restrict__ dst,
-                                             float* __restrict__ bias, int S, int n_pad) {
-  const int SG = S / 8;
-  const long long total = (long long)n_pad * 49 * SG;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int sg = (int)(i % SG);
-    const int tap = (int)((i / SG) % 49);
-    const int col = (int)(i / (49LL * SG));
-    const int y = col / 49, x = col - y * 49, m = tap / 7, n = tap - m * 7;
-    const int r = y - 6 * m + 3, t = x - 6 * n + 3;
-    float v[8];
-    if (col < 2401 && r >= 0 && r < HF_KP && t >= 0 && t < HF_KP) {
-      const float* src = kf + ((long long)r * HF_KP + t) * S + sg * 8;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = src[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = 0.f;
-    }
-    store8<T>(dst + (long long)col * (49 * S) + tap * S + sg * 8, v, 8);
-    if (i < n_pad) bias[i] = out_b[0];
-  }
-}
-
-constexpr int HF_PK = 384;                  // 361 taps of K padded to a multiple of the K-chunk (64 bf16 / 32 fp32 elements)
 
 // Pm[(f, m, n)][(r+3)*19 + t+3] = dz[f, 6m+r, 6n+t] for r, t in [-3, 15] inside the map, else 0; columns 361 .. 383 zero
 template <typename T>
@@ -156,22 +138,24 @@ static __global__ void head_unfold_f1_kernel(const float* __restrict__ dk, const
   df1[i] = acc;
 }
 
-// dH[p,q,k] = sum_{a,b,s} F1[a,b,k,s] dK[2a+p, 2b+q, s]        (one block per (p,q), thread = k x 4 slices of s)
+// dH[p,q,k] += sum_s F1[a,b,k,s] dK[2a+p, 2b+q, s]: block = ((p,q), (a,b)), thread = k x 4 contiguous quarters of s (16-byte
+// loads); dh zeroed by the caller
 static __global__ __launch_bounds__(256) void head_unfold_h_kernel(const float* __restrict__ dk, const float* __restrict__ f1,
                                                                   float* __restrict__ dh, int S) {
   __shared__ float red[256];
-  const int pq = blockIdx.x, p = pq / HF_HP, q = pq % HF_HP;
+  const int pq = blockIdx.x, p = pq / HF_HP, q = pq % HF_HP, ab = blockIdx.y, a = ab / 5, b = ab % 5;
   const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int S4 = S / 4;                                       // floats per quarter (S is a multiple of 64)
+  const f32x4* dkr = (const f32x4*)(dk + ((long long)(2 * a + p) * HF_KP + 2 * b + q) * S + sl * S4);
+  const f32x4* fr = (const f32x4*)(f1 + ((long long)ab * 64 + k) * S + sl * S4);
   float acc = 0.f;
-  for (int ab = 0; ab < 25; ++ab) {
-    const int a = ab / 5, b = ab % 5;
-    const float* dkr = dk + ((long long)(2 * a + p) * HF_KP + 2 * b + q) * S;
-    const float* fr = f1 + ((long long)ab * 64 + k) * S;
-    for (int s = sl; s < S; s += 4) acc += fr[s] * dkr[s];
+  for (int i = 0; i < S4 / 4; ++i) {
+    const f32x4 x = fr[i], y = dkr[i];
+    acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < 64) dh[pq * 64 + k] = red[k] + red[64 + k] + red[128 + k] + red[192 + k];
+  if (threadIdx.x < 64) atomicAdd(dh + pq * 64 + k, red[k] + red[64 + k] + red[128 + k] + red[192 + k]);
 }
 
 // dF2[a',b',c,k] = sum_{a,b} G[a,b,c] dH[a'+a-3, b'+b-3, k]    (dh index p+3 = a'+a)
@@ -186,18 +170,28 @@ static __global__ void head_unfold_f2_kernel(const float* __restrict__ dh, const
 }
 
 // dGp[6-a, 6-b, c] = dG[a,b,c] = sum_{a',b',k} F2[a',b',c,k] dH[a'+a-3, b'+b-3, k]     (flipped: what head_unfold_grads_kernel reads)
-static __global__ void head_unfold_g_kernel(const float* __restrict__ dh, const float* __restrict__ f2, float* __restrict__ dgp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 49 * 32) return;
-  const int c = i % 32, tap = i / 32, a = tap / 7, b = tap % 7;
+// block = tap (a,b), thread = (c, slice of 8 k)
+static __global__ __launch_bounds__(256) void head_unfold_g_kernel(const float* __restrict__ dh, const float* __restrict__ f2,
+                                                                  float* __restrict__ dgp) {
+  __shared__ float red[256];
+  const int tap = blockIdx.x, a = tap / 7, b = tap % 7;
+  const int c = threadIdx.x & 31, ks = threadIdx.x >> 5;
   float acc = 0.f;
   for (int ab = 0; ab < 25; ++ab) {
     const int a1 = ab / 5, b1 = ab % 5;
-    const float* fr = f2 + ((long long)ab * 32 + c) * 64;
-    const float* dr = dh + ((a1 + a) * HF_HP + b1 + b) * 64;
-    for (int k = 0; k < 64; ++k) acc += fr[k] * dr[k];
+    const float* fr = f2 + ((long long)ab * 32 + c) * 64 + ks * 8;
+    const float* dr = dh + ((a1 + a) * HF_HP + b1 + b) * 64 + ks * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += fr[k] * dr[k];
   }
-  dgp[((6 - a) * 7 + (6 - b)) * 32 + c] = acc;
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j * 32 + c];
+    dgp[((6 - a) * 7 + (6 - b)) * 32 + c] = t;
+  }
 }
 
 }  // namespace rgp

@@ -222,11 +222,15 @@ int seq_impl(rgp_grcn* g, hipStream_t s) {
 
 template <typename T>
 int head_impl(rgp_grcn* g, float* logits, hipStream_t s) {
-  if (g->fold_head) {                                          // head_fold.hip.h: logits = BN(h) x Wd + out_b, one launch
+  if (g->fold_head) {                                          // head_fold.hip.h: Z = BN(h) x K^T, then col2im (+ out_b)
     IgemmParams p = make_params(g->hfold, g->ws + g->hbn.off, g->ws, g->F);
-    EpiParams e = make_epi(g->hfold, logits, g->ws);
-    e.bias = (const float*)(g->ws + g->hf_bias.off);
-    return launch_igemm<T, 1, 1, EpiStore<float, true, false>>(p, e, s);
+    EpiParams e = make_epi(g->hfold, g->ws + g->hf_z.off, g->ws);
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+    const long long total = (long long)g->F * 2401;
+    head_col2im_kernel<<<(int)std::min<long long>((total + 255) / 256, 8192), 256, 0, s>>>((const float*)(g->ws + g->hf_z.off), g->out_b,
+                                                                                        logits, total);
+    RGP_HIP(hipGetLastError());
+    return RGP_OK;
   }
   for (const ConvDesc& d : g->d1) {
     IgemmParams p = make_params(d, g->ws + g->hbn.off, g->ws, g->F);
@@ -268,14 +272,14 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_HIP(hipGetLastError());
   RGP_TRY(pk.add(g->d3t, (const float*)(ws + g->gtoep.off), 16, 0));
   if (g->fold_head) {
-    // the whole head as one matrix (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1 -> the packed GEMM filter
+    // the head as one 19x19 stride-6 transposed convolution (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1
     float* hf = (float*)(ws + g->hf_h.off);
     float* kf = (float*)(ws + g->hf_k.off);
     head_fold_h_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(gf, w->up_weight2, hf);
-    head_fold_k_kernel<<<(HF_KP * HF_KP * S + 255) / 256, 256, 0, s>>>(hf, w->up_weight1, kf, S);
-    head_fold_pack_kernel<T><<<2048, 256, 0, s>>>(kf, w->out_b, (T*)(ws + g->hfold.w_off), (float*)(ws + g->hf_bias.off), S,
-                                                  g->hfold.n_pad());
+    RGP_HIP(hipMemsetAsync(kf, 0, g->hf_k.bytes, s));
+    head_fold_k_kernel<<<dim3(HF_KP * HF_KP, 5), 128, 0, s>>>(hf, w->up_weight1, kf, S);
     RGP_HIP(hipGetLastError());
+    RGP_TRY(pk.add(g->hfold, kf, HF_KP * HF_KP, 0));          // GEMM filter [(r,t)][s]; rows 361 .. 383 stay zero
   }
   RGP_TRY(pk.flush());
   g->bn_gamma = w->bn_gamma;
@@ -382,15 +386,12 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
     d.s_tap = 16LL * 704; d.s_n = 704; d.s_c = 1;           // gtoep [u][n][x'*32 + c]
   }
   if (g->fold_head) {
-    // the folded head (head_fold.hip.h): one GEMM row per frame, K = the 49 pixels x S channels of the padded BN(h) image,
-    // N = the 2401 pixels of the logit map
+    // the folded head (head_fold.hip.h): GEMM rows = the 7x7 positions of the padded BN(h) image, K = S, N = the 19x19 taps
     ConvDesc& d = g->hfold;
-    d.Mw = 1; d.N = 2401; d.in_img_stride = 81LL * S; d.out_img_stride = 2401;
-    d.in_tab = {0}; d.out_tab = {0};
-    std::vector<int> tapoff, fidx;
-    for (int m = 0; m < 7; ++m) for (int n = 0; n < 7; ++n) { tapoff.push_back(((m + 1) * 9 + n + 1) * S); fidx.push_back(m * 7 + n); }
-    ok &= build_k_schedule(d, tapoff, fidx, S, dtype);
-    d.s_tap = 0; d.s_n = 0; d.s_c = 0;                          // (packed by head_fold_pack_kernel, not by pack_filter)
+    d.Mw = 49; d.N = HF_PK; d.in_img_stride = 81LL * S; d.out_img_stride = 49LL * HF_PK;
+    for (int m = 0; m < 7; ++m) for (int n = 0; n < 7; ++n) { d.in_tab.push_back(((m + 1) * 9 + n + 1) * S); d.out_tab.push_back((m * 7 + n) * HF_PK); }
+    ok &= build_k_schedule(d, {0}, {0}, S, dtype);
+    d.s_tap = 0; d.s_n = S; d.s_c = 1;                          // source K [(r,t)][s]
   }
   if (!ok) { delete g; return set_err(RGP_EINVAL, "rgp_grcn_create: unsupported channel geometry P=%d S=%d", P, S); }
 
@@ -432,7 +433,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
   if (g->fold_head) {                                      // no intermediate maps: the fold's small fp32 work areas instead
     g->hf_h = take(a, (size_t)HF_HP * HF_HP * 64 * 4);
     g->hf_k = take(a, (size_t)HF_KP * HF_KP * S * 4);
-    g->hf_bias = take(a, (size_t)g->hfold.n_pad() * 4);
+    g->hf_z = take(a, (size_t)F * 49 * HF_PK * 4);
   } else {
     g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
     g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es + 4096);   // slack: the Toeplitz filter-gradient rows of pixel block 3 read past the last row

@@ -156,7 +156,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     const long long tot = M * HF_PK;
     head_fold_patches_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>(Fp(b->dz), Tp(b->pm), M);
     RGP_HIP(hipGetLastError());
-    RGP_HIP(hipMemsetAsync(ws + b->dkf.off, 0, b->dkf.bytes, s));
+    RGP_HIP(hipMemsetAsync(ws + b->dkf.off, 0, b->dhf.off + b->dhf.bytes - b->dkf.off, s));      // dK and dH (adjacent): atomics
     {
       WgradParams p = wg_params();
       p.X = Tp(b->pm); p.dY = Tp(g->hbn); p.dW = Fp(b->dkf);
@@ -169,9 +169,9 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     const float* hf = (const float*)(ws + g->hf_h.off);
     const float* gf = (const float*)(ws + g->gfold.off);
     head_unfold_f1_kernel<<<(25 * 64 * S + 255) / 256, 256, 0, s>>>(Fp(b->dkf), hf, (float*)gr->up_weight1, S);
-    head_unfold_h_kernel<<<HF_HP * HF_HP, 256, 0, s>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhf), S);
+    head_unfold_h_kernel<<<dim3(HF_HP * HF_HP, 25), 256, 0, s>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhf), S);
     head_unfold_f2_kernel<<<(25 * 32 * 64 + 255) / 256, 256, 0, s>>>(Fp(b->dhf), gf, (float*)gr->up_weight2);
-    head_unfold_g_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(Fp(b->dhf), b->w.up_weight2, Fp(b->dgp));
+    head_unfold_g_kernel<<<49, 256, 0, s>>>(Fp(b->dhf), b->w.up_weight2, Fp(b->dgp));
     head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
     RGP_HIP(hipGetLastError());
     {

@@ -17,11 +17,11 @@ struct rgp_grcn {
   std::vector<int> tab_pad9_P, tab_pad9_S, tab_pad27, tab_pad55, tab_lin49_3S, tab_lin49_S;
   size_t o_pad9_P = 0, o_pad9_S = 0, o_pad27 = 0, o_pad55 = 0, o_lin49_3S = 0, o_lin49_S = 0;
   Buf xt, E, xpre, hall, uall, rall, call, hp, rhp, hbn, D1, D2, gfold, frame_loss, gtoep, bias16;
-  // unless RGP_GRCN_UNFOLDED_HEAD: the three transposed convolutions + out_W folded into ONE 6272 x 2401 GEMM on BN(h)
-  // (head_fold.hip.h), forward and backward
+  // unless RGP_GRCN_UNFOLDED_HEAD: the three transposed convolutions + out_W folded into ONE 19x19 stride-6 transposed
+  // convolution on BN(h), run as GEMM + col2im (head_fold.hip.h), forward and backward
   bool fold_head = false;
   rgp::ConvDesc hfold;
-  Buf hf_h, hf_k, hf_bias;
+  Buf hf_h, hf_k, hf_z;            // H [11,11,64], K [361][S] fp32; Z [F*49][384] fp32 (the GEMM's output, gathered by col2im)
   Buf xch_h, xch_rh, seq_cnt;   // persistent ConvGRU sequence kernel: exchange images [groups][98][128] + phase counters
   int seq_nc = 0, seq_groups = 0;   // clips per group / groups (0 = the per-step path)
   unsigned* err_host = nullptr;     // pinned, device-visible error word: a persistent launch that timed out sets it
