@@ -72,13 +72,13 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
  *  RGP_GRCN_PER_STEP           run the ConvGRU recurrence and its BPTT as per-timestep launches even where the
  *                              persistent kernels apply (bf16, 128 state channels, <= 64 clips): the library's second
  *                              implementation of the recurrence, always used by f32 plans;
- *  RGP_GRCN_UNFOLDED_HEAD      inference plans run the saliency head (gaze_grcn.py:326-361) as ONE GEMM: the three
- *                              transposed convolutions and out_W have no bias or non-linearity between them and are
- *                              folded, exactly, into a 19x19 stride-6 filter on BN(h_t) when the weights are set.  With
- *                              this flag the plan runs the three stages instead (deconv1, deconv2, deconv3 . out_W), as
- *                              every training plan does (its filter gradients need the intermediate maps): the library's
- *                              second implementation of the head; the buffers "d1" / "d2" of rgp_grcn_read_buffer exist
- *                              only then. */
+ *  RGP_GRCN_UNFOLDED_HEAD      by default a plan runs the saliency head (gaze_grcn.py:326-361) folded: the three transposed
+ *                              convolutions and out_W have no bias or non-linearity between them and are combined, exactly,
+ *                              into one 19x19 stride-6 transposed convolution on BN(h_t) when the weights are set (GEMM +
+ *                              col2im forward; the backward is the chain rule through the fold and returns the gradients of
+ *                              weight1 / weight2 / weight3 / out_W themselves).  With this flag the plan runs the three
+ *                              stages one by one, forward and backward: the library's second implementation of the head;
+ *                              the buffers "d1" / "d2" of rgp_grcn_read_buffer exist only then. */
 #define RGP_GRCN_SAVE_FOR_BACKWARD 1
 #define RGP_GRCN_PER_STEP 2
 #define RGP_GRCN_UNFOLDED_HEAD 4

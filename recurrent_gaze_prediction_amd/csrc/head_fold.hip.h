@@ -66,25 +66,37 @@ static __global__ void head_fold_h_kernel(const float* __restrict__ g, const flo
   h[i] = s;
 }
 
-// K[(r+3)*19 + t+3][s] += sum_{b,k} F1[a,b,k,s] H[r-2a, t-2b, k]: block = ((r,t), a), thread = s; kf zeroed by the caller
-// (a thread per (r,t,s) looping over all 25 x 64 terms took 57 us: 180 blocks of serial loads; this form 1805 blocks of 320)
-static __global__ void head_fold_k_kernel(const float* __restrict__ h, const float* __restrict__ f1, float* __restrict__ kf, int S) {
+// K[(r+3)*19 + t+3][s] = sum_a part[a][(r,t)][s],  part[a][(r,t)][s] = sum_{b,k} F1[a,b,k,s] H[r-2a, t-2b, k]: block = ((r,t), a),
+// thread = s, then head_fold_sum_kernel adds the five parts in a fixed order (deterministic: two set_weights calls with the
+// same weights give the same bits; a thread per (r,t,s) looping over all 25 x 64 terms took 57 us -- 180 blocks of serial loads)
+static __global__ void head_fold_k_kernel(const float* __restrict__ h, const float* __restrict__ f1, float* __restrict__ part, int S) {
   const int rt = blockIdx.x, a = blockIdx.y;
   const int r = rt / HF_KP - 3, t = rt % HF_KP - 3;
   const int p = r - 2 * a;
-  if (p < -3 || p > 7) return;
+  float* dst = part + ((long long)a * HF_KP * HF_KP + rt) * S;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     float acc = 0.f;
-    for (int b = 0; b < 5; ++b) {
-      const int q = t - 2 * b;
-      if (q < -3 || q > 7) continue;
-      const float* hp = h + ((p + 3) * HF_HP + q + 3) * 64;
-      const float* fp = f1 + ((long long)(a * 5 + b) * 64) * S + s;
+    if (p >= -3 && p <= 7) {
+      for (int b = 0; b < 5; ++b) {
+        const int q = t - 2 * b;
+        if (q < -3 || q > 7) continue;
+        const float* hp = h + ((p + 3) * HF_HP + q + 3) * 64;
+        const float* fp = f1 + ((long long)(a * 5 + b) * 64) * S + s;
 #pragma unroll 8
-      for (int k = 0; k < 64; ++k) acc += hp[k] * fp[(long long)k * S];
+        for (int k = 0; k < 64; ++k) acc += hp[k] * fp[(long long)k * S];
+      }
     }
-    atomicAdd(kf + (long long)rt * S + s, acc);
+    dst[s] = acc;
   }
+}
+
+// out[i] = sum_{j < n_parts} part[j][i]   (fixed order)
+static __global__ void head_fold_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int n_parts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int j = 0; j < n_parts; ++j) acc += part[(long long)j * n + i];
+  out[i] = acc;
 }
 
 // Forward, second half (col2im of the transposed convolution): the GEMM  Z[(f,m,n)][(r,t)] = sum_s y[f,m,n,s] K[(r,t),s]
@@ -138,10 +150,10 @@ static __global__ void head_unfold_f1_kernel(const float* __restrict__ dk, const
   df1[i] = acc;
 }
 
-// dH[p,q,k] += sum_s F1[a,b,k,s] dK[2a+p, 2b+q, s]: block = ((p,q), (a,b)), thread = k x 4 contiguous quarters of s (16-byte
-// loads); dh zeroed by the caller
+// dH[p,q,k] = sum_{(a,b)} part[(a,b)][(p,q)][k],  part = sum_s F1[a,b,k,s] dK[2a+p, 2b+q, s]: block = ((p,q), (a,b)), thread = k x 4
+// contiguous quarters of s (16-byte loads); head_fold_sum_kernel adds the 25 parts in a fixed order
 static __global__ __launch_bounds__(256) void head_unfold_h_kernel(const float* __restrict__ dk, const float* __restrict__ f1,
-                                                                  float* __restrict__ dh, int S) {
+                                                                  float* __restrict__ part, int S) {
   __shared__ float red[256];
   const int pq = blockIdx.x, p = pq / HF_HP, q = pq % HF_HP, ab = blockIdx.y, a = ab / 5, b = ab % 5;
   const int k = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -155,7 +167,7 @@ static __global__ __launch_bounds__(256) void head_unfold_h_kernel(const float* 
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < 64) atomicAdd(dh + pq * 64 + k, red[k] + red[64 + k] + red[128 + k] + red[192 + k]);
+  if (threadIdx.x < 64) part[((long long)ab * HF_HP * HF_HP + pq) * 64 + k] = (red[k] + red[64 + k]) + (red[128 + k] + red[192 + k]);
 }
 
 // dF2[a',b',c,k] = sum_{a,b} G[a,b,c] dH[a'+a-3, b'+b-3, k]    (dh index p+3 = a'+a)

@@ -261,23 +261,26 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_TRY(pk.add(g->gzr, w->gru_Uz, S, 0));
   RGP_TRY(pk.add(g->gzr, w->gru_Ur, S, S));
   RGP_TRY(pk.add(g->gc, w->gru_U, S, 0));
-  for (size_t i = 0; i < g->d1_pack.size(); ++i) RGP_TRY(pk.add(g->d1_pack[i], w->up_weight1, 64, (int)(i % 3) * 64));   // column phase px = i % 3
-  for (size_t i = 0; i < g->d2_pack.size(); ++i) RGP_TRY(pk.add(g->d2_pack[i], w->up_weight2, 32, (int)(i % 2) * 32));
   float* gf = (float*)(ws + g->gfold.off);
   fold_head_filter_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(w->up_weight3, w->out_W, gf, 49, 12, 32);
   RGP_HIP(hipGetLastError());
-  RGP_TRY(pk.add(g->d3, gf, 1, 0));
-  toeplitz_head_filter_kernel<<<(7 * 16 * 704 + 255) / 256, 256, 0, s>>>(gf, w->out_b, (float*)(ws + g->gtoep.off),
-                                                                          (float*)(ws + g->bias16.off));
-  RGP_HIP(hipGetLastError());
-  RGP_TRY(pk.add(g->d3t, (const float*)(ws + g->gtoep.off), 16, 0));
+  if (!g->fold_head) {                                         // the three-stage head's operand filters
+    for (size_t i = 0; i < g->d1_pack.size(); ++i) RGP_TRY(pk.add(g->d1_pack[i], w->up_weight1, 64, (int)(i % 3) * 64));   // column phase px = i % 3
+    for (size_t i = 0; i < g->d2_pack.size(); ++i) RGP_TRY(pk.add(g->d2_pack[i], w->up_weight2, 32, (int)(i % 2) * 32));
+    RGP_TRY(pk.add(g->d3, gf, 1, 0));
+    toeplitz_head_filter_kernel<<<(7 * 16 * 704 + 255) / 256, 256, 0, s>>>(gf, w->out_b, (float*)(ws + g->gtoep.off),
+                                                                            (float*)(ws + g->bias16.off));
+    RGP_HIP(hipGetLastError());
+    RGP_TRY(pk.add(g->d3t, (const float*)(ws + g->gtoep.off), 16, 0));
+  }
   if (g->fold_head) {
     // the head as one 19x19 stride-6 transposed convolution (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1
     float* hf = (float*)(ws + g->hf_h.off);
     float* kf = (float*)(ws + g->hf_k.off);
     head_fold_h_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(gf, w->up_weight2, hf);
-    RGP_HIP(hipMemsetAsync(kf, 0, g->hf_k.bytes, s));
-    head_fold_k_kernel<<<dim3(HF_KP * HF_KP, 5), 128, 0, s>>>(hf, w->up_weight1, kf, S);
+    float* part = (float*)(ws + g->hf_part.off);
+    head_fold_k_kernel<<<dim3(HF_KP * HF_KP, 5), 128, 0, s>>>(hf, w->up_weight1, part, S);
+    head_fold_sum_kernel<<<(HF_KP * HF_KP * S + 255) / 256, 256, 0, s>>>(part, kf, HF_KP * HF_KP * S, 5);
     RGP_HIP(hipGetLastError());
     RGP_TRY(pk.add(g->hfold, kf, HF_KP * HF_KP, 0));          // GEMM filter [(r,t)][s]; rows 361 .. 383 stay zero
   }
@@ -434,6 +437,7 @@ int rgp_grcn_create(rgp_grcn_t** plan, int batch, int n_steps, int dim_proj, int
     g->hf_h = take(a, (size_t)HF_HP * HF_HP * 64 * 4);
     g->hf_k = take(a, (size_t)HF_KP * HF_KP * S * 4);
     g->hf_z = take(a, (size_t)F * 49 * HF_PK * 4);
+    g->hf_part = take(a, (size_t)5 * HF_KP * HF_KP * S * 4);
   } else {
     g->D1 = take(a, (size_t)F * 27 * 27 * 64 * es);
     g->D2 = take(a, (size_t)F * 55 * 55 * 32 * es + 4096);   // slack: the Toeplitz filter-gradient rows of pixel block 3 read past the last row

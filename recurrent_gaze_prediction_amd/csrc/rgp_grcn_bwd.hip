@@ -24,7 +24,7 @@ struct GrcnBwd {
   ConvDesc b_d2, b_d1, b_c, b_zr, b_x;     // dgrad convolutions
   ConvDesc b_px;                           // projection input gradient: d rows = dE x W^T
   ConvDesc b_hf;                           // folded head (head_fold.hip.h): dy = Pm x K, rows = (frame, 7x7 position), K = 384
-  Buf pm, dkf, dhf;                        // its patches [F*49][384] T, dK [384][S] and dH [11,11,64] fp32
+  Buf pm, dkf, dhf, dhp;                   // its patches [F*49][384] T, dK [384][S], dH [11,11,64] and dH's 25 partial sums, fp32
   // gather tables [ntaps][Mw] (element offsets, -1 = zero) + offsets in the workspace
   std::vector<int> t_y, t_pad3S, t_pad2S, koff_c;
   size_t o_y = 0, o_pad3S = 0, o_pad2S = 0, o_koff_c = 0;
@@ -137,7 +137,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     }
   }
   RGP_HIP(hipMemsetAsync(ws + b->dE.off, 0, (size_t)P * sizeof(T), s));                    // dE's zero row
-  RGP_HIP(hipMemsetAsync(ws + b->dgp.off, 0, b->dgp.bytes, s));
+  if (!g->fold_head) RGP_HIP(hipMemsetAsync(ws + b->dgp.off, 0, b->dgp.bytes, s));      // (the folded path overwrites dgp)
 
   if (ext_dy) {
     // the gradient w.r.t. the (batch-normalised) states comes from outside (cascade: the stride-7
@@ -156,7 +156,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     const long long tot = M * HF_PK;
     head_fold_patches_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>(Fp(b->dz), Tp(b->pm), M);
     RGP_HIP(hipGetLastError());
-    RGP_HIP(hipMemsetAsync(ws + b->dkf.off, 0, b->dhf.off + b->dhf.bytes - b->dkf.off, s));      // dK and dH (adjacent): atomics
+    RGP_HIP(hipMemsetAsync(ws + b->dkf.off, 0, b->dkf.bytes, s));                                // dK: the wgrad's atomics
     {
       WgradParams p = wg_params();
       p.X = Tp(b->pm); p.dY = Tp(g->hbn); p.dW = Fp(b->dkf);
@@ -169,7 +169,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     const float* hf = (const float*)(ws + g->hf_h.off);
     const float* gf = (const float*)(ws + g->gfold.off);
     head_unfold_f1_kernel<<<(25 * 64 * S + 255) / 256, 256, 0, s>>>(Fp(b->dkf), hf, (float*)gr->up_weight1, S);
-    head_unfold_h_kernel<<<dim3(HF_HP * HF_HP, 25), 256, 0, s>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhf), S);
+    head_unfold_h_kernel<<<dim3(HF_HP * HF_HP, 25), 256, 0, s>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhp), S);
+    head_fold_sum_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(Fp(b->dhp), Fp(b->dhf), HF_HP * HF_HP * 64, 25);
     head_unfold_f2_kernel<<<(25 * 32 * 64 + 255) / 256, 256, 0, s>>>(Fp(b->dhf), gf, (float*)gr->up_weight2);
     head_unfold_g_kernel<<<49, 256, 0, s>>>(Fp(b->dhf), b->w.up_weight2, Fp(b->dgp));
     head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
@@ -364,8 +365,10 @@ int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   // (no memset: the areas are zero from bind time outside the positions a pack writes, rgp_grcn.hip set_weights_impl)
   RGP_TRY(pk.add(b->b_px, w->proj_c3d_W, 512, 0));            // d = 0: feature channels 0, 2, 4, ...
   RGP_TRY(pk.add(b->b_px, w->proj_c3d_W + P, 512, 512));      // d = 1: feature channels 1, 3, 5, ...
-  RGP_TRY(pk.add(b->b_d2, w->up_weight2, 64, 0));
-  RGP_TRY(pk.add(b->b_d1, w->up_weight1, S, 0));
+  if (!g->fold_head) {
+    RGP_TRY(pk.add(b->b_d2, w->up_weight2, 64, 0));
+    RGP_TRY(pk.add(b->b_d1, w->up_weight1, S, 0));
+  }
   RGP_TRY(pk.add(b->b_c, w->gru_U, S, 0));
   RGP_TRY(pk.add(b->b_zr, w->gru_Uz, S, 0, 0, 1));
   RGP_TRY(pk.add(b->b_zr, w->gru_Ur, S, 0, S, 1));
@@ -468,6 +471,7 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
     b->pm = take(a, (size_t)F * 49 * HF_PK * es);
     b->dkf = take(a, (size_t)HF_PK * S * 4);
     b->dhf = take(a, (size_t)HF_HP * HF_HP * 64 * 4);
+    b->dhp = take(a, (size_t)25 * HF_HP * HF_HP * 64 * 4);
   } else {
     b->dd2 = take(a, (size_t)F * 2401 * 32 * es + 4096);
     b->dd1 = take(a, (size_t)F * 529 * 64 * es + 4096);

@@ -21,6 +21,7 @@ struct rgp_grcn {
   // convolution on BN(h), run as GEMM + col2im (head_fold.hip.h), forward and backward
   bool fold_head = false;
   rgp::ConvDesc hfold;
+  Buf hf_part;                     // the five partial sums of K (summed in a fixed order)
   Buf hf_h, hf_k, hf_z;            // H [11,11,64], K [361][S] fp32; Z [F*49][384] fp32 (the GEMM's output, gathered by col2im)
   Buf xch_h, xch_rh, seq_cnt;   // persistent ConvGRU sequence kernel: exchange images [groups][98][128] + phase counters
   int seq_nc = 0, seq_groups = 0;   // clips per group / groups (0 = the per-step path)
