@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-4 profile set (run on the GPU box from the repo root): kernel stats of the driver-style bench and of the
 # head / train / fine-tune workloads, then separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ sets) of a short e2e run.
-# Output under gpurun_out/r04p/; scripts/pmc_summary.py condenses the PMC passes (-> profiles/r04p_pmc_summary.json).
+# Output under gpurun_out/r04/; scripts/pmc_summary.py condenses the PMC passes (-> profiles/r04_pmc_summary.json).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04p
+O=gpurun_out/r04
 mkdir -p $O
 python3 bench.py --steps 20 --warmup 5 > $O/bench_e2e.json 2> $O/bench_e2e.err || exit 1
 echo "bench done"
@@ -26,4 +26,8 @@ python3 scripts/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
 # the raw per-dispatch traces are large: keep the stats / summaries
 find $O -name "*kernel_trace.csv" -size +4M -delete
 find $O -name "*counter_collection.csv" -size +4M -delete
+ls $O
+# round 4 extras: the data-parallel probes at N = 1 (no collective runs; the keys the driver's N > 1 command will carry)
+python3 bench.py --steps 5 --dp-train-probe on --dp-finetune-probe on --no-cpu-baseline > $O/bench_probes.json 2> $O/bench_probes.err || echo "probes failed"
+python3 scripts/bench_configs.py > $O/configs.json 2> $O/configs.err || echo "configs failed"
 ls $O
