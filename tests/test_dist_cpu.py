@@ -8,6 +8,14 @@ import pytest
 
 from recurrent_gaze_prediction_amd import dist as rdist
 
+
+def _free_port():
+    """A TCP port nobody listens on right now (a fixed rendezvous port fails when an earlier run's socket still lingers)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -46,7 +54,7 @@ def test_two_rank_gloo_control_plane(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)],
+                          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
@@ -136,7 +144,7 @@ def _run_dp(tmp_path, world, port):
 def test_two_rank_dp_step_reproduces_the_full_batch_step(tmp_path):
     import numpy as np
     one = _run_dp(tmp_path, 1, 0)[0]
-    two = sorted(_run_dp(tmp_path, 2, 29541), key=lambda r: r['rank'])
+    two = sorted(_run_dp(tmp_path, 2, _free_port()), key=lambda r: r['rank'])
     assert [r['world'] for r in two] == [2, 2]
     for r in two:        # every rank ends with the weights of the single-process run on all 8 clips
         assert np.allclose(r['W'], one['W'], rtol=0, atol=1e-12)
