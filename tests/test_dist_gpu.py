@@ -43,9 +43,13 @@ def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
     """World size 2 with the real engines (gloo, both ranks on this GPU): tests/dp2_gpu_child.py."""
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp2_gpu_child.py')
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
-    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a port nobody listens on right now
+        sk.bind(('127.0.0.1', 0))
+        port = str(sk.getsockname()[1])
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29547', child],
+                        '--master-addr', '127.0.0.1', '--master-port', port, child],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
