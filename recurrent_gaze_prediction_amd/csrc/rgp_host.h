@@ -303,7 +303,12 @@ IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
     // persistent walk costs more than the bytes saved, and the 256x128 kernel's 1568 tiles run faster)
     const int wide = p.tile128 ? 0 : dev_knob("RGP_WIDE", 3);
     if (ksplit == 1 && p.nk >= 2 && p.nk <= 256) {
-      if ((wide & 1) && p.N % 256 == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 1024) return TILE_WIDE_256x256;
+      const long long wtiles = (long long)((p.M + 255) / 256) * (p.N / 256);
+      if ((wide & 1) && p.N % 256 == 0 && wtiles >= 1024) return TILE_WIDE_256x256;
+      // short reductions (the head's projection: K = 1024, 16 K-tiles): a 256 x 128 tile ingests 48 KB per K-tile of 4.2 MFLOP and
+      // is bound by the CU's LDS-DMA ingest (66-73 GB/s), not by its rounds: 256 x 256 tiles move two thirds of the bytes per
+      // FLOP and win even at 1.5 rounds (392 tiles at 1024 frames: 82 -> see DESIGN.md us)
+      if ((wide & 1) && p.N % 256 == 0 && p.nk <= 32 && wtiles >= 256 && dev_knob("RGP_WIDE_SHORTK", 1)) return TILE_WIDE_256x256;
       if ((wide & 2) && p.N == 128 && (p.M + 511) / 512 >= 1024) return TILE_WIDE_512x128;
     }
   }
