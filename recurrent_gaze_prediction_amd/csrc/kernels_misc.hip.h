@@ -14,7 +14,12 @@ __global__ __launch_bounds__(256) void nchw_to_rows_kernel(const float* __restri
   __shared__ float tile[64][50];
   const int f = blockIdx.y, c0 = blockIdx.x * 64;
   const float* src = x + ((long long)f * C + c0) * 49;
-  for (int i = threadIdx.x; i < 64 * 49; i += 256) tile[i / 49][i % 49] = src[i];
+  // 64 x 49 floats = 784 contiguous 16-byte pieces (the block's slice starts at a multiple of 12 544 bytes)
+  for (int q = threadIdx.x; q < 64 * 49 / 4; q += 256) {
+    const f32x4 v = *(const f32x4*)(src + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = 4 * q + k; tile[i / 49][i % 49] = v[k]; }
+  }
   __syncthreads();
   for (int it = threadIdx.x; it < 49 * 8; it += 256) {
     const int p = it >> 3, cg = it & 7;
