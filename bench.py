@@ -266,6 +266,9 @@ def main():
                     'kernel': kname,
                     'launches': int(calls), 'avg_launch_ms': round(ms / max(calls, 1), 4),
                     'algorithmic_gflop_per_launch': round(flops / max(calls, 1) / 1e9, 3)}
+        if kname == 'head':
+            roofline['note'] = ('algorithmic FLOPs of the three transposed convolutions + out_W (164.65 MFLOP per frame, SURVEY 8d); the '
+                                'library runs them as their exact fold, which issues 4.8 MFLOP per frame: not an MFMA utilisation')
         flops_frame = HEAD_FLOPS_FRAME + (C3D_FLOPS_FRAME if c3d is not None else 0.0)
         if ft is not None:
             from recurrent_gaze_prediction_amd.finetune import flops_per_frame_train
