@@ -262,7 +262,7 @@ def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2,
 
 
 def dp_finetune_probe(dist, device, rank=0, batch=16, n_steps=35, steps=3, warmup=1, dtype='bf16', seed=0, c3d_chunk=None,
-                      model='cascade'):
+                      model='cascade', per_step=False):
     """BASELINE config 5 at its per-GPU shape (16 clips x T = 35 per rank = 560 C3D windows) as ONE data-parallel
     training step: C3D forward -> cascade forward -> l2 loss -> cascade backward -> conv-stack backward, the gradient
     leaving in NINE buckets through GradBucketReducer's side stream as their producers are queued (the cascade's
@@ -288,7 +288,8 @@ def dp_finetune_probe(dist, device, rank=0, batch=16, n_steps=35, steps=3, warmu
         frames = torch.rand(batch, n_steps, 98, 98, 3, device=dev, generator=g)
         run = lambda: m.train_step(video, frames, gt, 1e-4)
     else:
-        m = EndToEndGaze(batch, n_steps, dtype=dtype, device=dev, max_windows=chunk, seed=seed + 1)
+        # (per_step: ConvGRU as per-timestep launches -- required when several ranks share one device, tests only)
+        m = EndToEndGaze(batch, n_steps, dtype=dtype, device=dev, max_windows=chunk, seed=seed + 1, per_step=per_step)
         gt = (gt / gt.sum((-1, -2), keepdim=True)).contiguous()
         run = lambda: m.train_step(video, gt, 1e-4)
     m.attach_process_group(dist)

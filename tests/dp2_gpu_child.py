@@ -70,8 +70,12 @@ def main():
     rdist.barrier(dist, dev)
     # bench.py's N > 1 leg (dist.dp_train_probe) under world size 2: both ranks must be seen and stay in sync
     probe = rdist.dp_train_probe(dist, dev, rank=rank, batch=2, n_steps=3, steps=2, warmup=1, per_step=True)
+    # ... and bench.py's config-5 leg (dist.dp_finetune_probe) in its gaze_grcn form: 3 head + 8 conv buckets per step; every
+    # rank trains on its own clip, so equal weights afterwards mean the averaged gradients were applied on both
+    ft = rdist.dp_finetune_probe(dist, dev, rank=rank, batch=1, n_steps=2, steps=2, warmup=1, model='grcn', per_step=True)
     if rank == 0:
         out['probe'] = probe
+        out['finetune_probe'] = ft
         print(json.dumps(out))
     dist.destroy_process_group()
 

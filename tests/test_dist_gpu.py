@@ -62,3 +62,6 @@ def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
     assert pr['world'] == 2 and pr['ranks_seen'] == 2 and pr['replicas_in_sync'], pr
     assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6, pr
     assert pr['convgru'] == 'per-step launches', pr
+    ft = out['finetune_probe']
+    assert ft['world'] == 2 and ft['ranks_seen'] == 2 and ft['replicas_in_sync'] and ft['finite'], ft
+    assert ft['allreduce_buckets_per_step'] == 11 and ft['allreduce_bytes_per_step'] == ft['gradient_bytes'], ft
