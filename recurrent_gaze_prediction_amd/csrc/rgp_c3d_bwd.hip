@@ -278,7 +278,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         q.db = grads + b.grad_b;
         q.n_windows = n;
         RGP_TRY(ensure_dyn_smem((const void*)conv1a_wgrad_bf16_kernel, W1_SMEM));
-        conv1a_wgrad_bf16_kernel<<<256, 512, W1_SMEM, s>>>(q);
+        int n_cu_w1 = 0;
+        RGP_TRY(device_cu_count(&n_cu_w1));
+        conv1a_wgrad_bf16_kernel<<<2 * n_cu_w1, 512, W1_SMEM, s>>>(q);   // two blocks per CU (119 VGPRs, 2 x 81 792 B of LDS): more fetches in flight
         RGP_HIP(hipGetLastError());
       } else if (i == 0) {
         p.dW = (float*)(ws + c->dw1_off);
