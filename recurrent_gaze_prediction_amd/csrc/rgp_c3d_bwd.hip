@@ -177,13 +177,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ buf, 
   const int CG = C / 8;
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG, RL = 256 / CG;
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long r = (long long)blockIdx.x * RL + rl; r < rows_total; r += (long long)gridDim.x * RL) {
-    const long long img = r / Mw;
-    const int ml = (int)(r - img * Mw);
-    float v[8];
-    mp_load8(buf + img * img_stride + tab[ml] + cg * 8, v);        // (16-byte load: kernels_misc.hip.h)
+  // four rows per thread and iteration: four independent 16-byte loads in flight (one per iteration read 0.8 GB of conv3a's dYpre
+  // at 3.2 TB/s: latency-bound)
+  const long long step = (long long)gridDim.x * RL;
+  for (long long r0 = (long long)blockIdx.x * RL + rl; r0 < rows_total; r0 += 4 * step) {
+    float v[4][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bsum[k] += v[k];
+    for (int u = 0; u < 4; ++u) {
+      const long long r = r0 + u * step;
+      if (r < rows_total) {
+        const long long img = r / Mw;
+        const int ml = (int)(r - img * Mw);
+        mp_load8(buf + img * img_stride + tab[ml] + cg * 8, v[u]);        // (16-byte load: kernels_misc.hip.h)
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[u][k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bsum[k] += v[u][k];
   }
   block_colsum(bsum, cg, rl, RL, C, db);
 }
