@@ -1,5 +1,6 @@
 """Dev: C3D per-layer times of two builds of librgp_hip.so on one box, alternating processes.
-usage: dev_ab_lib.py <other .so> [rounds]   (child mode: dev_ab_lib.py --child <.so>)"""
+usage: dev_ab_lib.py <other .so> [rounds]   (child mode: dev_ab_lib.py --child <.so>)
+(older builds are kept under prev/, which .gpurunignore keeps off the GPU box: take the entry out for an A/B run)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
