@@ -119,3 +119,45 @@ def test_engine_refuses_to_run_without_gpu():
     from recurrent_gaze_prediction_amd.engine import GrcnEngine
     with pytest.raises(_lib.RgpError):
         GrcnEngine(1, 1)
+
+
+def test_header_is_valid_c_and_a_c_program_links_the_library(tmp_path):
+    """The drop-in boundary is a C ABI: include/rgp.h must compile as C99 (no C++-isms, no torch types) and a plain C
+    program must link librgp_hip.so and drive the host-only entry points (plan creation, validation, error strings,
+    workspace queries) -- what a maintainer's cgo / JNI / ctypes stub sees."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    src = tmp_path / 'abi.c'
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "rgp.h"
+int main(void) {
+  rgp_grcn_t* g = 0;
+  rgp_c3d_t* c = 0;
+  if (rgp_version() < 100) return 1;
+  if (rgp_grcn_create(&g, 8, 35, 512, 128, RGP_BF16, RGP_GRCN_SAVE_FOR_BACKWARD) != RGP_OK) return 2;
+  if (rgp_grcn_workspace_bytes(g) == 0) return 3;
+  if (rgp_grcn_wait_grads(g, RGP_GRCN_GRADS_TOP, 0) != RGP_ESTATE) return 4;         /* no backward has run */
+  if (!strstr(rgp_last_error(), "backward")) return 5;
+  if (rgp_grcn_create(&g, 0, 35, 512, 128, RGP_BF16, 0) != RGP_EINVAL) return 6;     /* empty batch */
+  if (rgp_c3d_create_ex(&c, 16, RGP_BF16, 0) != RGP_OK) return 7;
+  if (rgp_c3d_param_elems(c) != 27655936u + 0u) return 8;                            /* 27.66 M conv parameters (SURVEY 8a row C) */
+  printf("%s\n", rgp_c3d_layer_kernel_name(c, 1, 16));
+  rgp_c3d_destroy(c);
+  return 0;
+}
+''')
+    inc = os.path.join(ROOT, 'include')
+    libdir = os.path.join(ROOT, 'recurrent_gaze_prediction_amd')
+    assert subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-fsyntax-only', '-I', inc, str(src)],
+                          capture_output=True, text=True).returncode == 0
+    exe = tmp_path / 'abi'
+    r = subprocess.run(['gcc', '-std=c99', '-I', inc, str(src), '-o', str(exe), '-L', libdir, '-l:librgp_hip.so',
+                        '-Wl,-rpath,' + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-1000:])
+    assert r.stdout.strip().startswith('conv_patch')
