@@ -59,8 +59,10 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='train workload: replay the step as HIP graphs')
     ap.add_argument('--dp-train-probe', choices=['auto', 'on', 'off'], default='auto',
                     help="after the headline timing also time BASELINE config 4's data-parallel training step (B=8 x T=35 per "
-                         "GPU: fwd + bwd + bucketed RCCL all-reduce + clip + Adam) and report it under 'dp_train'; auto = when "
-                         "more than one rank runs, so that the driver's N>1 command exercises the collective path")
+                         "GPU: fwd + bwd + bucketed RCCL all-reduce + clip + Adam) and the same step at config 3's per-GPU shape "
+                         "(B=64 x T=16: full-chip persistent ConvGRU launches next to the collectives), reported under 'dp_train' / "
+                         "'dp_train_b64'; auto = when more than one rank runs, so that the driver's N>1 command exercises the "
+                         "collective path")
     ap.add_argument('--dp-finetune-probe', choices=['auto', 'on', 'off'], default='auto',
                     help="also time BASELINE config 5's data-parallel JOINT training step at its per-GPU shape (16 clips x T=35: "
                          "C3D + cascade, the gradient leaving in nine buckets on a side stream under the backward) with and "
@@ -193,7 +195,9 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = rdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    mine = time.perf_counter() - t0
+    elapsed = rdist.max_over_ranks(dist, mine, dev)
+    per_rank_ms = [round(t / args.steps * 1e3, 4) for t in rdist.gather_over_ranks(dist, mine, dev)]   # which GPU set the MAX
     hprof = head.profile_read()
     cprof = c3d.profile_read() if c3d is not None else {}
     if ft is not None:
@@ -203,9 +207,14 @@ def main():
 
     # ---- N > 1: the driver's one command must also exercise the collective path (inference has none): BASELINE config 4's
     # training step at its per-GPU shape, after the headline timing, reported in extra keys
-    dp_train = None
+    dp_train = dp_train_b64 = None
     if args.dp_train_probe == 'on' or (args.dp_train_probe == 'auto' and world > 1):
         dp_train = rdist.dp_train_probe(dist, dev, rank=rank, batch=8, n_steps=35, steps=max(5, args.steps), warmup=2, dtype=args.dtype)
+        # ... and at config 3's per-GPU shape (64 clips x T = 16): the persistent ConvGRU forward and BPTT launches then take
+        # all 256 CUs (one workgroup each), the one interaction with a live RCCL kernel no smaller shape shows; the probe
+        # reports whether a launch lost a member and fell back ('convgru_fallbacks', 0 expected: the library releases no
+        # gradient bucket ahead of a full-chip launch, include/rgp.h)
+        dp_train_b64 = rdist.dp_train_probe(dist, dev, rank=rank, batch=64, n_steps=16, steps=max(5, args.steps), warmup=2, dtype=args.dtype)
     # ... and the one place the design overlaps communication with compute: config 5's joint step (122.7 MB of conv + head
     # gradient buckets + the cascade's 216 MB), timed with and without the collectives
     dp_finetune = None
@@ -277,6 +286,7 @@ def main():
             'metric': 'frames/sec (49x49 saliency maps), gaze_grcn 16-frame clips',
             'value': round(value, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'per_rank_ms': per_rank_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': ('gaze_grcn END-TO-END TRAINING step: synthetic 16x112x112x3 windows -> C3D conv1a-5b (arg-max '
@@ -304,6 +314,7 @@ def main():
         }
         if dp_train is not None:
             out['dp_train'] = dp_train
+            out['dp_train_b64'] = dp_train_b64
         if dp_finetune is not None:
             out['dp_finetune'] = dp_finetune
         if world == 1 and not args.no_cpu_baseline and args.workload in ('e2e', 'head'):
@@ -313,7 +324,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for probe in (dp_train, dp_finetune):
+    for probe in (dp_train, dp_train_b64, dp_finetune):
         if probe is not None and (probe['ranks_seen'] != args.gpus or not probe['replicas_in_sync']):
             raise SystemExit('bench.py: a data-parallel probe saw %d ranks for --gpus %d (replicas in sync: %s)'
                              % (probe['ranks_seen'], args.gpus, probe['replicas_in_sync']))

@@ -155,11 +155,25 @@ int rgp_grcn_backward_from_states(rgp_grcn_t* plan, const float* d_states, const
  * of gradients is final, in this order -- RGP_GRCN_GRADS_TOP: bn_gamma, bn_beta, up_weight1..3, out_W, out_b (before
  * the BPTT starts); RGP_GRCN_GRADS_GRU: the six ConvGRU filters; RGP_GRCN_GRADS_PROJ: proj_c3d_W / _b (the end of the
  * backward).  rgp_grcn_wait_grads makes `waiting_stream` wait for that event, so the host can issue the all-reduce
- * of the group's slice there while the rest of the backward is still running.  RGP_ESTATE before the first backward. */
+ * of the group's slice there while the rest of the backward is still running.  RGP_ESTATE before the first backward,
+ * and after a backward that was captured into a HIP graph (nothing is recorded during capture; a replay has no events). */
 #define RGP_GRCN_GRADS_TOP 0
 #define RGP_GRCN_GRADS_GRU 1
 #define RGP_GRCN_GRADS_PROJ 2
 int rgp_grcn_wait_grads(rgp_grcn_t* plan, int group, rgp_stream_t waiting_stream);
+/* Co-residency rule for that overlap.  The persistent BPTT launch occupies one CU per workgroup (8 per group of 1 - 2
+ * clips; 157 KB of LDS each, so nothing else fits beside one) and cannot make progress until ALL of them are resident.
+ * A collective started before it may hold CUs for as long as the slowest peer rank takes.  Therefore the TOP group's
+ * event is recorded ahead of the BPTT launch only when that launch needs at most (CUs of the device -
+ * RGP_RCCL_CU_RESERVE) workgroups (on a 256-CU MI355X: up to 24 clips per GPU, e.g. BASELINE config 4's 8); larger
+ * per-GPU batches (config 3's 64 clips = 256 workgroups) record it BEHIND the launch, so no collective of this step can
+ * run next to it.  Per-step plans (RGP_GRCN_PER_STEP, f32) always release it early.  rgp_grcn_grads_top_early reports
+ * which of the two the plan does on the current device: 1 = before the BPTT, 0 = behind it. */
+#define RGP_RCCL_CU_RESERVE 64
+int rgp_grcn_grads_top_early(const rgp_grcn_t* plan);
+/* Workgroups (= CUs) a persistent ConvGRU / BPTT launch of this plan occupies on the current device; 0 if the plan runs
+ * the recurrence as per-timestep launches (RGP_GRCN_PER_STEP, f32, other widths, more clips than the device has CUs for). */
+int rgp_grcn_persistent_workgroups(const rgp_grcn_t* plan);
 
 /* After rgp_grcn_backward: the gradient w.r.t. the network input, d_rows [B*T*49, 1024] fp32 in the column
  * order of the conv5b rows (d*512 + c) -- what rgp_c3d_backward takes when the conv stack is fine-tuned

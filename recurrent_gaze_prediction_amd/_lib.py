@@ -149,6 +149,8 @@ SIGNATURES = {
     'rgp_cascade_set_dropout': (c_int, [c_void_p, ctypes.c_float, c_void_p]),
     'rgp_c3d_wait_layer_grads': (c_int, [c_void_p, c_int, c_void_p]),
     'rgp_grcn_wait_grads': (c_int, [c_void_p, c_int, c_void_p]),
+    'rgp_grcn_grads_top_early': (c_int, [c_void_p]),
+    'rgp_grcn_persistent_workgroups': (c_int, [c_void_p]),
     'rgp_grcn_profile_enable': (c_int, [c_void_p, c_int]),
     'rgp_grcn_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     'rgp_c3d_profile_enable': (c_int, [c_void_p, c_int]),

@@ -126,11 +126,7 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_bptt_kernel(const BpttP
       __hip_atomic_fetch_add(cnt + ph, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // bounded: ~1 s; a workgroup that timed out once stops waiting altogether (its results are poisoned below), so a
       // group with a missing member costs a second, not a second per phase
-      int spins = 0;
-      while (!s_timeout && __hip_atomic_load(cnt + ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 20)) { s_timeout = 1; break; }
-      }
+      if (!s_timeout && !seq_wait_phase(cnt + ph)) s_timeout = 1;
     }
     __syncthreads();
   };

@@ -67,6 +67,21 @@ __device__ __forceinline__ void seq_st_sc1(void* base, unsigned bytes, unsigned 
 
 constexpr int SEQ_NT = 256;                          // 4 waves = one per SIMD, each with the whole 512-register file
 
+// Bounded wait for a group's phase counter (one lane).  The bound is a DEADLINE on the constant-rate real-time counter
+// (s_memrealtime: 100 MHz on gfx950, independent of the shader clock), not an iteration count: how long an iteration takes
+// depends on the clock the chip holds and on what else loads the same L2 channel (e.g. a concurrent RCCL kernel), so a
+// count (rounds 2-4: 2^20 iterations) bounds nothing in particular.  ~1 s of wall clock; the clock is read every 64th poll.
+constexpr unsigned long long SEQ_DEADLINE_TICKS = 100ull * 1000 * 1000;
+__device__ __forceinline__ bool seq_wait_phase(const unsigned* cnt) {      // true = all 8 members arrived, false = deadline passed
+  if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 8u) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (unsigned spins = 1;; ++spins) {
+    __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 8u) return true;
+    if ((spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > SEQ_DEADLINE_TICKS) return false;
+  }
+}
+
 // NF = 16-row fragments of a group: 4 (one clip, 49 rows) or 7 (two clips, 98 rows); a template parameter so that the
 // MFMA loops carry no run-time guards (measured: wave-uniform `if (f < MF)` around the reads / MFMAs cost 25 %).
 template <int NF>
@@ -186,11 +201,7 @@ static __global__ __launch_bounds__(SEQ_NT) void convgru_seq_kernel(const SeqPar
     if (tid == 0) {
       // bounded: ~1 s; a workgroup that timed out once stops waiting altogether (its results are poisoned below), so a
       // group with a missing member costs a second, not a second per phase
-      int spins = 0;
-      while (!s_timeout && __hip_atomic_load(cnt + ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 20)) { s_timeout = 1; break; }
-      }
+      if (!s_timeout && !seq_wait_phase(cnt + ph)) s_timeout = 1;
     }
     __syncthreads();
     for (int i = tid; i < rows * 16; i += SEQ_NT) {

@@ -134,6 +134,14 @@ bool seq_persistent_ok(const rgp_grcn* g) {
   return g->seq_groups > 0 && device_cu_count(&n_cu) == RGP_OK && g->seq_groups * 8 <= n_cu;
 }
 
+// Whether the TOP gradient group may be released (its all-reduce started on another stream) BEFORE the persistent BPTT
+// launch: only when that launch leaves at least RGP_RCCL_CU_RESERVE CUs to the collective's workgroups.
+bool grads_top_early(const rgp_grcn* g) {
+  int n_cu = 0;
+  if (g->seq_groups <= 0 || device_cu_count(&n_cu) != RGP_OK) return true;      // per-step plans: nothing needs co-residency
+  return g->seq_groups * 8 <= n_cu - RGP_RCCL_CU_RESERVE;
+}
+
 namespace {
 
 // All T steps in one persistent launch (convgru_seq.hip.h): recurrent filters resident in registers, state on chip.

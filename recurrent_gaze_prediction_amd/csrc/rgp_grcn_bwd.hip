@@ -243,10 +243,17 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const float inv = 1.0f / sqrtf(1.0f + 1e-3f);
   bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(Fp(b->dy), Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma,
                                                   (float*)gr->bn_beta, Fp(b->dh_head), B, T_, S, inv);
-  if (mark) RGP_HIP(hipEventRecord(b->grad_ev[0], s));                 // bn_gamma/beta, up_weight1..3, out_W, out_b are final
   // 6. BPTT: t = T-1 .. 0 -- one persistent launch where the plan allows it (bf16, the reference cell, <= 64 clips)
   const int ew_blocks = (int)std::min<size_t>((st + 255) / 256, 4096);
   const bool persistent = sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1);
+  // bn_gamma/beta, up_weight1..3, out_W, out_b are final here.  Their event lets the host start the group's all-reduce on
+  // another stream -- i.e. an RCCL kernel that runs NEXT TO the BPTT launch.  That launch needs all its workgroups resident
+  // together, one per CU (157 KB of LDS each): a collective's workgroup that reaches a CU first keeps a member off it until
+  // the collective ends, which takes as long as the slowest peer rank.  So the early release is for launches that leave CUs
+  // free (config 4: 8 clips per GPU = 64 workgroups); a launch that needs more than n_cu - RGP_RCCL_CU_RESERVE CUs
+  // releases the group only behind itself (include/rgp.h, rgp_grcn_wait_grads).
+  const bool top_early = !persistent || grads_top_early(g);
+  if (mark && top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], s));
   if (persistent) {
     RGP_HIP(hipMemsetAsync(ws + b->bptt_cnt.off, 0, b->bptt_cnt.bytes, s));      // phase counters: zeroed EVERY call
     BpttParams q;
@@ -273,6 +280,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_HIP(hipGetLastError());
     RGP_TRY(guard.commit());
   }
+  if (mark && !top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], s));     // full-chip launch: the TOP group leaves behind it
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
     gru_bwd1_kernel<T><<<ew_blocks, 256, 0, s>>>(Fp(b->dh_head) + (size_t)t * st, Fp(b->dh_carry), h_prev,
@@ -352,6 +360,10 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   if (mark) {
     RGP_HIP(hipEventRecord(b->grad_ev[2], s));
     b->grad_ev_recorded = true;
+  } else {
+    // captured into a graph: nothing was recorded, and events of an earlier eager backward say nothing about a replay --
+    // rgp_grcn_wait_grads must not hand them out (RGP_ESTATE until the next eager backward)
+    b->grad_ev_recorded = false;
   }
   return RGP_OK;
 }
@@ -556,6 +568,15 @@ int rgp_grcn_backward_from_states(rgp_grcn_t* g, const float* d_states, const rg
   hipStream_t s = (hipStream_t)stream;
   return g->dtype == RGP_BF16 ? backward_impl<bf16_t>(g, nullptr, nullptr, nullptr, grads, 0, s, d_states)
                               : backward_impl<float>(g, nullptr, nullptr, nullptr, grads, 0, s, d_states);
+}
+
+int rgp_grcn_persistent_workgroups(const rgp_grcn_t* g) {
+  return (g && g->dtype == RGP_BF16 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1)) ? g->seq_groups * 8 : 0;
+}
+
+int rgp_grcn_grads_top_early(const rgp_grcn_t* g) {
+  if (!g) return 0;
+  return rgp_grcn_persistent_workgroups(g) > 0 ? (grads_top_early(g) ? 1 : 0) : 1;
 }
 
 int rgp_grcn_wait_grads(rgp_grcn_t* g, int group, rgp_stream_t waiting_stream) {

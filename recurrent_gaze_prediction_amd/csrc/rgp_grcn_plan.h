@@ -45,6 +45,8 @@ inline Buf take(rgp::Arena& a, size_t bytes) {
 
 // rgp_grcn.hip: the persistent ConvGRU kernels apply to this plan on the current device
 bool seq_persistent_ok(const rgp_grcn* g);
+// ... and its persistent BPTT launch leaves RGP_RCCL_CU_RESERVE CUs free (the TOP gradient group may leave before it)
+bool grads_top_early(const rgp_grcn* g);
 // rgp_grcn_bwd.hip
 // returns RGP_ETIMEOUT (and clears the word) if a persistent launch of this plan reported a lost group member
 int grcn_check_error(rgp_grcn* g);

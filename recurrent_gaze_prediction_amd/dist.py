@@ -76,6 +76,16 @@ def sum_over_ranks(dist, value, device='cpu'):
     return float(t.item())
 
 
+def gather_over_ranks(dist, value, device='cpu'):
+    """[value of rank 0, value of rank 1, ...] (python floats; one all-gather): which rank set the MAX."""
+    if dist is None:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return [float(t.item()) for t in got]
+
+
 def shard_clips(n_clips, rank, world):
     """Contiguous, balanced [lo, hi) range of clip indices owned by `rank`."""
     base, extra = divmod(int(n_clips), int(world))
@@ -196,26 +206,51 @@ def engine_status_all_ranks(dist, engine, device):
         raise err if err is not None else RuntimeError('a peer rank reported a failed persistent ConvGRU launch')
 
 
-def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2, dtype='bf16', seed=0, per_step=False):
-    """BASELINE config 4 at its per-GPU shape (B = 8 clips x T = 35 per rank) as ONE data-parallel training step:
-    gaze_grcn forward + backward on the rank's own clips -> GradBucketReducer (the flat 12 MB fp32 gradient, RCCL AVG
-    on a side stream) -> finish -> clip_by_global_norm(10) + TF-Adam (base.py:286-297).  Timed like the headline
-    (barrier, `steps` steps, barrier, MAX over ranks).  Every rank starts from the same weights and sees different
-    clips, so after the steps the weights must still be identical on all ranks -- checked with a MAX/MIN all-reduce of
-    a checksum.  Returns a dict (same on every rank).
+def engine_timeouts_all_ranks(dist, engine, device):
+    """Number of ranks whose engine reports RGP_ETIMEOUT (a persistent ConvGRU launch that lost a group member) since
+    the last check -- the same number on every rank (one SUM all-reduce), so all ranks fall back together; any other
+    error is raised on all ranks."""
+    from . import _lib
+    mine, err = 0, None
+    try:
+        engine.status()
+    except _lib.RgpError as exc:
+        if exc.code == _lib.RGP_ETIMEOUT:
+            mine = 1
+        else:
+            err = exc
+    if not all_ranks_ok(dist, err is None, device):
+        raise err if err is not None else RuntimeError('a peer rank reported a failed engine')
+    return int(round(sum_over_ranks(dist, mine, device)))
+
+
+def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2, dtype='bf16', seed=0, per_step=False,
+                   inject_fault=None):
+    """gaze_grcn's data-parallel TRAINING step at a per-GPU shape (default: BASELINE config 4's B = 8 clips x T = 35 per
+    rank; bench.py also runs config 3's B = 64 x T = 16, whose persistent ConvGRU / BPTT launches fill the chip):
+    forward + backward on the rank's own clips -> GradBucketReducer (the flat 12 MB fp32 gradient, RCCL AVG on a side
+    stream) -> finish -> clip_by_global_norm(10) + TF-Adam (base.py:286-297).  Timed like the headline (barrier, `steps`
+    steps, barrier, MAX over ranks; 'per_rank_ms' = every rank's own clock).  Every rank starts from the same weights and
+    sees different clips, so after the steps the weights must still be identical on all ranks -- checked with a MAX/MIN
+    all-reduce of a checksum.  Returns a dict (same on every rank).
 
     The gradient goes out as THREE buckets in the order the backward finishes them (GrcnEngine.grad_buckets: batch-norm +
-    upsampling + output layer before the BPTT starts, the ConvGRU filters, the projection), so only the last 2.1 MB
-    start after the backward has ended.  per_step=True: ConvGRU recurrence and BPTT as per-timestep launches
-    (RGP_GRCN_PER_STEP) -- REQUIRED when several ranks share one device (tests), where two persistent launches would
-    compete for the CUs (include/rgp.h)."""
+    upsampling + output layer, the ConvGRU filters, the projection).  Whether the first leaves BEFORE the persistent BPTT
+    launch or behind it is the library's co-residency rule (include/rgp.h, rgp_grcn_grads_top_early: before, when the
+    launch leaves CUs to the collective -- B <= 24 clips per GPU); reported as 'top_bucket_release'.
+
+    'convgru_fallbacks': if a persistent launch loses a group member (RGP_ETIMEOUT: another kernel held one of its CUs for
+    the whole deadline), ALL ranks -- they agree through one all-reduce -- rebuild the engine on per-timestep launches,
+    restore the initial weights (the poisoned gradient has been averaged into every replica by then) and repeat warm-up
+    and timing; the count of ranks that reported a time-out is returned (0 expected) and 'convgru' says which plan the
+    reported time belongs to.  per_step=True: per-timestep launches from the start -- REQUIRED when several ranks share
+    one device (tests), where two persistent launches would compete for the CUs (include/rgp.h).
+    inject_fault ('seq' | 'bptt', tests): the first timed step's launch loses a member on rank 0."""
     import time
     from . import synthetic as syn
     from .engine import GrcnEngine
     dev = torch.device(device)
     world = dist.get_world_size() if dist is not None else 1
-    head = GrcnEngine(batch, n_steps, dtype=dtype, save_for_backward=True, device=dev, per_step=per_step)
-    head.set_weights(syn.grcn_params(seed + 1, n_steps))
     g = torch.Generator(device=dev)
     g.manual_seed(4321 + int(rank))
     x = torch.relu(torch.randn(batch, n_steps, 1024, 7, 7, device=dev, generator=g))
@@ -224,39 +259,59 @@ def dp_train_probe(dist, device, rank=0, batch=8, n_steps=35, steps=5, warmup=2,
     logits = torch.empty(batch, n_steps, 49, 49, device=dev)
     probs = torch.empty_like(logits)
     reducer = GradBucketReducer(dist, dev)
-    k = [0]
-    gnorm = [None]
+    fallbacks = 0
+    while True:
+        head = GrcnEngine(batch, n_steps, dtype=dtype, save_for_backward=True, device=dev, per_step=per_step)
+        head.set_weights(syn.grcn_params(seed + 1, n_steps))
+        k = [0]
+        gnorm = [None]
 
-    def step():
-        head.forward(x, out_logits=logits, out_probs=probs)
-        head.backward(logits, probs, gt)
-        reducer.reduce_buckets(head.grad_buckets())
-        reducer.finish()
-        gnorm[0] = head.adam_step(k[0], 1e-4 * 0.8 ** (k[0] // 500), max_grad_norm=10.0)
-        k[0] += 1
+        def step():
+            head.forward(x, out_logits=logits, out_probs=probs)
+            head.backward(logits, probs, gt)
+            reducer.reduce_buckets(head.grad_buckets())
+            reducer.finish()
+            gnorm[0] = head.adam_step(k[0], 1e-4 * 0.8 ** (k[0] // 500), max_grad_norm=10.0)
+            k[0] += 1
 
-    for _ in range(warmup):
-        step()
-    barrier(dist, dev)
-    bytes0 = reducer.bytes_reduced
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier(dist, dev)
-    elapsed = max_over_ranks(dist, time.perf_counter() - t0, dev)
-    engine_status_all_ranks(dist, head, dev)
+        for _ in range(warmup):
+            step()
+        barrier(dist, dev)
+        if inject_fault and not per_step and fallbacks == 0 and rank == 0:
+            head.inject_fault(inject_fault)
+        bytes0 = reducer.bytes_reduced
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier(dist, dev)
+        mine = time.perf_counter() - t0
+        elapsed = max_over_ranks(dist, mine, dev)
+        per_rank = gather_over_ranks(dist, mine, dev)
+        lost = engine_timeouts_all_ranks(dist, head, dev)
+        if lost == 0:
+            break
+        if per_step:
+            raise RuntimeError('dp_train_probe: RGP_ETIMEOUT from a per-step plan')
+        fallbacks += lost
+        per_step = True
+    persistent = not per_step and head.persistent
     seen = ranks_seen(dist, rank, dev)
     # replicas stay replicas: same weights on every rank after the averaged steps
     chk = float(head.flat_params.double().abs().sum().item())
     hi = max_over_ranks(dist, chk, dev)
     lo = -max_over_ranks(dist, -chk, dev)
-    return {'workload': 'gaze_grcn data-parallel TRAINING step (BASELINE config 4 per-GPU shape): fwd + bwd + bucketed '
-                        'gradient all-reduce (mean, side stream) + clip_by_global_norm(10) + TF-Adam',
+    return {'workload': 'gaze_grcn data-parallel TRAINING step (per-GPU shape %d clips x T = %d): fwd + bwd + bucketed '
+                        'gradient all-reduce (mean, side stream) + clip_by_global_norm(10) + TF-Adam' % (batch, n_steps),
             'clips_per_gpu': batch, 'n_lstm_steps': n_steps, 'steps': steps, 'warmup': warmup, 'dtype': dtype,
             'ms_per_step': round(elapsed / steps * 1e3, 4),
+            'per_rank_ms': [round(t / steps * 1e3, 4) for t in per_rank],
             'frames_per_s': round(world * batch * n_steps * steps / elapsed, 1),
             'allreduce_bytes_per_step': int((reducer.bytes_reduced - bytes0) // max(steps, 1)),
-            'allreduce_buckets_per_step': 3, 'convgru': 'per-step launches' if per_step else 'persistent',
+            'allreduce_buckets_per_step': 3,
+            'convgru': ('persistent' if persistent else 'per-step launches') + (' (fallback after RGP_ETIMEOUT)' if fallbacks else ''),
+            'convgru_workgroups': head.persistent_workgroups if persistent else 0,
+            'convgru_fallbacks': fallbacks,
+            'top_bucket_release': 'before the BPTT launch' if head.grads_top_early else 'behind the BPTT launch',
             'backend': _backend(dist), 'ranks_seen': seen, 'world': world,
             'grad_norm_last': float(gnorm[0].item()), 'replicas_in_sync': bool(abs(hi - lo) <= 1e-9 * max(abs(hi), 1.0))}
 
@@ -294,6 +349,7 @@ def dp_finetune_probe(dist, device, rank=0, batch=16, n_steps=35, steps=3, warmu
         run = lambda: m.train_step(video, gt, 1e-4)
     m.attach_process_group(dist)
     last = [None, None]
+    per_rank = [None]
 
     def timed(k):
         barrier(dist, dev)
@@ -301,15 +357,24 @@ def dp_finetune_probe(dist, device, rank=0, batch=16, n_steps=35, steps=3, warmu
         for _ in range(k):
             last[0], last[1] = run()
         barrier(dist, dev)
-        return max_over_ranks(dist, time.perf_counter() - t0, dev)
+        mine = time.perf_counter() - t0
+        per_rank[0] = [round(t / k * 1e3, 3) for t in gather_over_ranks(dist, mine, dev)]
+        return max_over_ranks(dist, mine, dev)
 
     for _ in range(warmup):
         run()
     bytes0, n0 = m.reducer.bytes_reduced, m.reducer.buckets_reduced
     elapsed = timed(steps)
+    per_rank_ms = per_rank[0]
     per_step_bytes = int((m.reducer.bytes_reduced - bytes0) // max(steps, 1))
     per_step_buckets = int((m.reducer.buckets_reduced - n0) // max(steps, 1))
     finite = bool(torch.isfinite(last[0])) and bool(torch.isfinite(last[1]))
+    # a persistent ConvGRU launch that lost a member (model='grcn' only: the cascade's cells run per step) shows up as a
+    # non-finite loss as well; the count of ranks that saw it is reported, the probe does not re-run
+    fallbacks = 0
+    for e in m.engines:
+        if callable(getattr(e, 'status', None)) and hasattr(e, 'grad_buckets'):
+            fallbacks += engine_timeouts_all_ranks(dist, e, dev)
     chk = float(sum(e.flat_params.double().abs().sum().item() for e in m.engines))
     hi = max_over_ranks(dist, chk, dev)
     lo = -max_over_ranks(dist, -chk, dev)
@@ -325,7 +390,8 @@ def dp_finetune_probe(dist, device, rank=0, batch=16, n_steps=35, steps=3, warmu
                          % ('gaze_grcn_cascade' if model == 'cascade' else 'gaze_grcn head')),
             'clips_per_gpu': batch, 'n_lstm_steps': n_steps, 'windows_per_gpu': F, 'c3d_chunk': chunk, 'steps': steps,
             'warmup': warmup, 'dtype': dtype,
-            'ms_per_step': round(elapsed / steps * 1e3, 3),
+            'ms_per_step': round(elapsed / steps * 1e3, 3), 'per_rank_ms': per_rank_ms,
+            'convgru_fallbacks': fallbacks,
             'ms_per_step_no_allreduce': round(elapsed_off / steps * 1e3, 3),
             'exposed_allreduce_ms_per_step': round((elapsed - elapsed_off) / steps * 1e3, 3),
             'frames_per_s': round(world * F * steps / elapsed, 1),

@@ -320,6 +320,23 @@ class GrcnEngine(object):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.rgp_grcn_status(self._h, _stream_ptr(self.device)))
 
+    @property
+    def persistent_workgroups(self):
+        """CUs a persistent ConvGRU / BPTT launch of this plan occupies (0: the recurrence runs as per-timestep launches)."""
+        with torch.cuda.device(self.device):
+            return int(self.lib.rgp_grcn_persistent_workgroups(self._h))
+
+    @property
+    def persistent(self):
+        return self.persistent_workgroups > 0
+
+    @property
+    def grads_top_early(self):
+        """Whether the first gradient bucket (grad_buckets()[0]) is released before the BPTT launch (include/rgp.h: only
+        when that launch leaves RGP_RCCL_CU_RESERVE CUs to the collective) or behind it."""
+        with torch.cuda.device(self.device):
+            return bool(self.lib.rgp_grcn_grads_top_early(self._h))
+
     def inject_fault(self, kind):
         """Test hook (rgp_grcn_inject_fault): kind 'seq' / 'bptt' -- the next persistent launch loses a member."""
         _lib.check(self.lib.rgp_grcn_inject_fault(self._h, {'seq': _lib.RGP_FAULT_SEQ_LOST_MEMBER,

@@ -141,8 +141,14 @@ class ModelBase(object):
         if ck.get('flip_rng_state') is not None and getattr(self, 'flip_rng', None) is not None:
             self.flip_rng.set_state(ck['flip_rng_state'])
             self.flip_seed = ck.get('flip_seed', getattr(self, 'flip_seed', None))
-        sites, saved = self._dropout_sites(), ck.get('dropout', [])
-        if len(saved) != len(sites):
+        sites, saved = self._dropout_sites(), ck.get('dropout')
+        if saved is None:
+            # a checkpoint written before the dropout state was stored: keep this rank's freshly derived key, draws = 0
+            if sites:
+                log.warning(" [Checkpoint] %s holds no dropout state: %d dropout site(s) start a new mask stream",
+                            checkpoint_path, len(sites))
+            saved = []
+        elif len(saved) != len(sites):
             raise ValueError('checkpoint holds %d dropout site(s), this model has %d' % (len(saved), len(sites)))
         from .. import dist as rdist
         from .gaze_rnn import DROPOUT_RANK_STRIDE

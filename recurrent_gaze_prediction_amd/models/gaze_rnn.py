@@ -186,18 +186,36 @@ class GazePredictionGRU(ModelBase):
         from .. import dist as rdist
         self.dist = dist
         self.reducer = rdist.GradBucketReducer(dist, self.session.device) if dist is not None else None
+        # plans with persistent ConvGRU launches can fail asynchronously (RGP_ETIMEOUT): the ranks then agree on the outcome
+        # of every backward before they enter the collectives.  Decided ONCE, from the plan every rank was built with (a rank
+        # that later falls back to per-step launches keeps answering), so the ranks' collective sequences stay the same.
+        self._dp_agree = dist is not None and bool(getattr(self.engine, 'persistent', False))
 
     def _train_op(self, logits, probs, labels_dev):
         loss_type = 'l2' if self.config.loss_type == 'l2' else 'xentropy'
         self.engine.backward(logits, probs, labels_dev, loss_type)
-        if self._status_or_recover():             # the BPTT launch timed out (NaN gradients): redo the step's forward
-            z, p = self.engine.forward(self._last_input, **self._last_forward_kw)[:2]      # and backward on the new engine
-            self.engine.backward(z, p, labels_dev, loss_type)
-            self._status_or_recover(final=True)
+        err = None
+        try:
+            if self._status_or_recover():         # the BPTT launch timed out (NaN gradients): redo the step's forward
+                z, p = self.engine.forward(self._last_input, **self._last_forward_kw)[:2]      # and backward on the new engine
+                self.engine.backward(z, p, labels_dev, loss_type)
+                self._status_or_recover(final=True)
+        except Exception as exc:                  # noqa: BLE001 -- re-raised below, on every rank
+            err = exc
+        if getattr(self, '_dp_agree', False):
+            # a rank that raises here must not leave its peers blocked in the all-reduce: everybody raises, or nobody
+            from .. import dist as rdist
+            if not rdist.all_ranks_ok(self.dist, err is None, self.session.device):
+                raise err if err is not None else RuntimeError('a peer rank failed in its backward pass')
+        elif err is not None:
+            raise err
         if self.reducer is not None:
             buckets = getattr(self.engine, 'grad_buckets', None)
             if callable(buckets):
-                self.reducer.reduce_buckets(buckets())        # in completion order, the first before the BPTT has ended
+                # in completion order on the reducer's side stream.  (On this path the status check above has already waited
+                # for the backward, so nothing overlaps; engines driven directly -- dist.dp_train_probe, finetune.py --
+                # skip that wait and do overlap.)
+                self.reducer.reduce_buckets(buckets())
             else:
                 self.reducer.reduce(self.engine.flat_grads)   # in place, fp32, mean over ranks
             self.reducer.finish()
@@ -250,6 +268,8 @@ class GazePredictionGRU(ModelBase):
         status = getattr(self.engine, 'status', None)
         if not callable(status):
             return False
+        if not getattr(self.engine, 'persistent', True):
+            return False          # per-timestep launches cannot time out: no host wait for the stream either
         from .. import _lib
         try:
             status()

@@ -63,6 +63,8 @@ def main():
     out['bytes_reduced_per_step'] = res[1][4] // 3
     # bench.py's N > 1 leg (dist.dp_train_probe) through RCCL with the forced one-rank group, at config 4's shape
     out['probe'] = rdist.dp_train_probe(dist, dev, rank=0, batch=8, n_steps=35, steps=3, warmup=1)
+    # ... at config 3's per-GPU shape: 256-workgroup persistent forward + BPTT launches with the three-bucket reducer live
+    out['probe_b64'] = rdist.dp_train_probe(dist, dev, rank=0, batch=64, n_steps=16, steps=3, warmup=1)
     # ... and the config-5 leg (dist.dp_finetune_probe: nine + buckets through the side stream), at a small shape
     out['finetune_probe'] = rdist.dp_finetune_probe(dist, dev, rank=0, batch=1, n_steps=2, steps=2, warmup=1, model='cascade')
     out['finetune_probe_grcn'] = rdist.dp_finetune_probe(dist, dev, rank=0, batch=1, n_steps=2, steps=2, warmup=1, model='grcn')

@@ -30,12 +30,21 @@ def test_rccl_one_rank_group_runs_the_reducer(gpu):
     assert pr['backend'] == 'nccl' and pr['ranks_seen'] == 1 and pr['replicas_in_sync'], pr
     assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6 and pr['ms_per_step'] > 0 and pr['grad_norm_last'] > 0, pr
     assert pr['allreduce_buckets_per_step'] == 3 and pr['convgru'] == 'persistent', pr
+    # config 4's 8 clips per GPU leave 192 CUs to the collective: the first bucket leaves ahead of the BPTT launch
+    assert pr['convgru_workgroups'] == 64 and pr['top_bucket_release'] == 'before the BPTT launch', pr
+    assert pr['convgru_fallbacks'] == 0 and len(pr['per_rank_ms']) == 1 and pr['per_rank_ms'][0] <= pr['ms_per_step'] + 1e-3, pr
+    # config 3's 64 clips per GPU: full-chip persistent launches (256 workgroups) with the reducer live through RCCL
+    pb = out['probe_b64']
+    assert pb['backend'] == 'nccl' and pb['replicas_in_sync'] and pb['convgru'] == 'persistent' and pb['convgru_fallbacks'] == 0, pb
+    assert pb['convgru_workgroups'] == 256 and pb['top_bucket_release'] == 'behind the BPTT launch', pb
+    assert 11e6 < pb['allreduce_bytes_per_step'] < 13e6 and pb['grad_norm_last'] > 0, pb
     # config 5's leg: the cascade's flat buffer + eight conv buckets; the gaze_grcn variant: three head + eight conv buckets
     fp, fg = out['finetune_probe'], out['finetune_probe_grcn']
     for q, buckets in ((fp, 9), (fg, 11)):
         assert q['backend'] == 'nccl' and q['ranks_seen'] == 1 and q['replicas_in_sync'] and q['finite'], q
         assert q['allreduce_buckets_per_step'] == buckets and q['allreduce_bytes_per_step'] == q['gradient_bytes'], q
         assert q['ms_per_step'] > 0 and q['ms_per_step_no_allreduce'] > 0, q
+        assert q['convgru_fallbacks'] == 0 and len(q['per_rank_ms']) == 1, q
     assert fp['gradient_bytes'] > 300e6 and 120e6 < fg['gradient_bytes'] < 125e6, (fp, fg)
 
 
@@ -61,7 +70,55 @@ def test_two_ranks_on_half_batches_reproduce_the_full_batch_step(gpu):
     pr = out['probe']
     assert pr['world'] == 2 and pr['ranks_seen'] == 2 and pr['replicas_in_sync'], pr
     assert 11e6 < pr['allreduce_bytes_per_step'] < 13e6, pr
-    assert pr['convgru'] == 'per-step launches', pr
+    assert pr['convgru'] == 'per-step launches' and pr['convgru_fallbacks'] == 0 and pr['convgru_workgroups'] == 0, pr
+    assert len(pr['per_rank_ms']) == 2 and abs(max(pr['per_rank_ms']) - pr['ms_per_step']) < 1e-3, pr
     ft = out['finetune_probe']
     assert ft['world'] == 2 and ft['ranks_seen'] == 2 and ft['replicas_in_sync'] and ft['finite'], ft
     assert ft['allreduce_buckets_per_step'] == 11 and ft['allreduce_bytes_per_step'] == ft['gradient_bytes'], ft
+    assert len(ft['per_rank_ms']) == 2 and ft['convgru_fallbacks'] == 0, ft
+
+
+def test_probe_falls_back_and_says_so_when_a_persistent_launch_loses_a_member(gpu):
+    """bench.py's data-parallel probe under the one failure it exists to report: the BPTT launch of the first timed step
+    loses a workgroup (fault injection; on an 8-GPU node: a CU held by a collective for the whole deadline).  The probe
+    re-runs on per-timestep launches from the initial weights and reports the fall-back instead of a silent slower number."""
+    from recurrent_gaze_prediction_amd import dist as rdist
+    pr = rdist.dp_train_probe(None, gpu, rank=0, batch=2, n_steps=3, steps=2, warmup=1, inject_fault='bptt')
+    assert pr['convgru_fallbacks'] == 1 and pr['convgru'] == 'per-step launches (fallback after RGP_ETIMEOUT)', pr
+    assert pr['convgru_workgroups'] == 0 and pr['replicas_in_sync'] and pr['grad_norm_last'] > 0, pr
+    ok = rdist.dp_train_probe(None, gpu, rank=0, batch=2, n_steps=3, steps=2, warmup=1)
+    assert ok['convgru_fallbacks'] == 0 and ok['convgru'] == 'persistent' and ok['convgru_workgroups'] == 16, ok
+    # same seeds, same data: the fall-back run trained the same model (per-step and persistent kernels agree to bf16 rounding)
+    assert abs(ok['grad_norm_last'] - pr['grad_norm_last']) < 5e-2 * ok['grad_norm_last'], (ok, pr)
+
+
+def test_top_bucket_release_follows_the_co_residency_rule(gpu):
+    """include/rgp.h: the first gradient bucket is released ahead of the persistent BPTT launch only when that launch leaves
+    RGP_RCCL_CU_RESERVE (64) CUs free; the events are ordered accordingly on the stream."""
+    from recurrent_gaze_prediction_amd import synthetic as syn
+    from recurrent_gaze_prediction_amd.engine import GrcnEngine
+    import torch
+    n_cu = torch.cuda.get_device_properties(gpu).multi_processor_count
+    for B, per_step in ((8, False), (24, False), (25, False), (64, False), (64, True)):
+        eng = GrcnEngine(B, 2, dtype='bf16', save_for_backward=True, device=gpu, per_step=per_step)
+        wg = 0 if per_step else 8 * ((B + (B + 31) // 32 - 1) // ((B + 31) // 32))
+        assert eng.persistent_workgroups == wg, (B, per_step, eng.persistent_workgroups)
+        assert eng.grads_top_early == (per_step or wg <= n_cu - 64), (B, per_step, n_cu)
+    # the full-chip plan still delivers every bucket: gradients after reduce_buckets + finish on a side stream == flat_grads
+    eng = GrcnEngine(64, 2, dtype='bf16', save_for_backward=True, device=gpu)
+    eng.set_weights(syn.grcn_params(5, 2, gru_std=0.05, random_bn=True))
+    x = torch.tensor(syn.c3d_features(6, 64, 2), device=gpu)
+    gt = torch.rand(64, 2, 49, 49, device=gpu) + 1e-3
+    gt = (gt / gt.sum((-1, -2), keepdim=True)).contiguous()
+    z, p = eng.forward(x)
+    eng.backward(z, p, gt)
+    side = torch.cuda.Stream(gpu)
+    copies = []
+    with torch.cuda.stream(side):
+        for bucket, ready in eng.grad_buckets():
+            ready(side)
+            copies.append(bucket.clone())
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize()
+    eng.status()
+    assert torch.equal(torch.cat(copies), eng.flat_grads) and bool(torch.isfinite(eng.flat_grads).all())

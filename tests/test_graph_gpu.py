@@ -56,3 +56,25 @@ def test_graph_replay_sees_new_inputs(gpu):
     x.copy_(torch.tensor(syn.c3d_features(999, 2, 3), device=gpu))
     gs.step()
     assert float((gs.logits - l1).abs().max()) > 1e-3 and bool(torch.isfinite(gs.logits).all())
+
+
+def test_wait_grads_refuses_stale_events_after_a_captured_backward(gpu):
+    """a backward captured into a graph records no gradient events; the ones of an earlier eager backward say
+    nothing about a replay, so rgp_grcn_wait_grads must answer RGP_ESTATE until the next eager backward."""
+    from recurrent_gaze_prediction_amd import _lib
+    from recurrent_gaze_prediction_amd.graph import GraphedHeadTrainStep
+    eng, x, gt = _setup(gpu, 'bf16')
+    z, p = eng.forward(x)
+    eng.backward(z, p, gt)
+    side = torch.cuda.Stream(gpu)
+    for _, ready in eng.grad_buckets():
+        ready(side)                                   # eager backward: events exist
+    gs = GraphedHeadTrainStep(eng, x, gt, 1e-4)       # warm-up (eager, on a side stream) + capture
+    gs.step()
+    with pytest.raises(_lib.RgpError) as ei:
+        eng.grad_buckets()[0][1](side)
+    assert ei.value.code == -4                        # RGP_ESTATE
+    z, p = eng.forward(x)
+    eng.backward(z, p, gt)
+    eng.grad_buckets()[0][1](side)                    # valid again
+    torch.cuda.synchronize()

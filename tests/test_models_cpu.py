@@ -102,3 +102,22 @@ def test_checkpoint_resume_keeps_dropout_streams_distinct_per_rank(tmp_path, mon
     two = _stub_model(tmp_path / 'two', n_sites=2)
     with pytest.raises(ValueError, match='dropout site'):
         two.load_model_from_checkpoint_file(path)
+
+
+def test_checkpoint_without_dropout_state_still_loads(tmp_path, monkeypatch):
+    """a checkpoint written before the 'dropout' key existed loads into a model WITH dropout sites -- the
+    sites keep this rank's freshly derived key and start at draw 0; only a PRESENT key of the wrong length is an error."""
+    import torch
+    monkeypatch.setenv('RANK', '0')
+    m0 = _stub_model(tmp_path / 'a')
+    path = m0.save_model_checkpoint(m0.train_dir)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    del ck['dropout']
+    old = str(tmp_path / 'old.pt')
+    torch.save(ck, old)
+    m = _stub_model(tmp_path / 'b')
+    fresh = m.sites[0].seed
+    m.sites[0].draws = 0
+    m.load_model_from_checkpoint_file(old)
+    assert m.sites[0].seed == fresh and m.sites[0].draws == 0
+    assert np.array_equal(m.vars['w'], np.arange(4, dtype=np.float32))
