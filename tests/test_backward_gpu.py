@@ -71,10 +71,11 @@ def test_bptt_through_35_steps_matches_autograd(gpu, dtype, tol, head):
     assert float(np.linalg.norm(ref['GRU_Conv_U'].numpy())) > 1e-6
 
 
-@pytest.mark.parametrize('B,T', [(3, 4), (33, 3)])
+@pytest.mark.parametrize('B,T', [(3, 4), (33, 3), (8, 35)])
 def test_persistent_bptt_group_shapes(gpu, B, T):
-    """The persistent BPTT kernel with a group count that is not a multiple of 8 (B = 3) and with two clips per group
-    and a ragged last group (B = 33), against float64 autograd."""
+    """The persistent BPTT kernel with a group count that is not a multiple of 8 (B = 3), with two clips per group
+    and a ragged last group (B = 33), and at BASELINE config 4's per-GPU shape (8 clips x T = 35: 64 workgroups through 35
+    steps), against float64 autograd."""
     from recurrent_gaze_prediction_amd.engine import GrcnEngine
     P, S = 512, 128
     p, x, g = case(300 + B, B, T, P, S)

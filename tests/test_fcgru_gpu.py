@@ -94,3 +94,36 @@ def test_config2_training_steps_through_the_model_api(gpu, tmp_path):
     assert np.isfinite(model.loss) and model.loss < loss0, (loss0, model.loss)
     after = model.state_dict()
     assert not np.array_equal(after['gates_kernel'], before['gates_kernel'])
+
+
+def test_fcgru_at_config2_shape_matches_oracle_forward_and_backward(gpu):
+    """BASELINE config 2's own shape: 64 clips x T = 16, 7x7 maps, fp32 -- the recurrence GEMMs then have 64 live rows
+    (igemm_skinny_kernel's full row tile; the small cases above run 2 - 3).  Forward against the float64 oracle, the
+    gradients of all 8 variables against float64 autograd of the same loss (models/gaze_rnn.py:211-360)."""
+    from recurrent_gaze_prediction_amd.engine import FcGruEngine
+    B, T, GH = 64, 16, 7
+    p = syn.fcgru_params(151, GH, GH)
+    p['gates_bias'] = p['gates_bias'] + np.linspace(-0.3, 0.3, p['gates_bias'].size).astype(np.float32)
+    x = syn.c3d_features(152, B, T)
+    rs = np.random.RandomState(153)
+    gt = rs.rand(B, T, GH, GH).astype(np.float32)
+    gt /= gt.sum(axis=(2, 3), keepdims=True)
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+        logits_ref = torch_ref.fcgru_forward(torch.tensor(x, dtype=torch.float64), pt, GH, GH)
+        torch_ref.gaze_loss(logits_ref, torch.tensor(gt, dtype=torch.float64), 'xentropy').backward()
+    finally:
+        torch.set_num_threads(old)
+    eng = FcGruEngine(B, T, (GH, GH), dtype='f32', device=gpu, save_for_backward=True)
+    eng.set_weights(p)
+    logits, probs = eng.forward(torch.tensor(x, device=gpu))
+    ref = logits_ref.detach().numpy()
+    # every clip on its own scale: a row tile that dropped or repeated a clip would show in that clip
+    per_clip = np.abs(logits.cpu().numpy().astype(np.float64) - ref).reshape(B, -1).max(1) / np.abs(ref).reshape(B, -1).max(1)
+    assert per_clip.max() < TOL['f32'], (int(per_clip.argmax()), float(per_clip.max()))
+    grads = eng.backward(logits, probs, torch.tensor(gt, device=gpu), 'xentropy')
+    errs = {k: rel_err(grads[k].cpu().numpy(), pt[k].grad.numpy()) for k in p}
+    assert all(np.abs(pt[k].grad.numpy()).max() > 0 for k in p)
+    assert max(errs.values()) < 5e-4, errs

@@ -127,3 +127,54 @@ def test_config5_joint_training_steps(gpu):
     assert losses[-1] < losses[0], losses
     assert float((m.c3d.flat_params - w0).abs().max()) > 0 and float((m.head.flat_params - h0).abs().max()) > 0
     assert torch.equal(m.head.weights['shallownet.fc1_w'], s0)
+
+
+def test_config5_at_its_per_gpu_shape(gpu):
+    """BASELINE config 5 at the shape ONE GPU of the 8 runs: 16 clips x T = 35 = 560 C3D windows through the conv stack
+    (one chunk), the two-level cascade and the joint backward (about 45 GB of workspaces) -- until round 5 only
+    scripts/bench_config5.py ran it.  (i) The cascade of that run, fed the conv features the device produced, against the
+    float64 oracle for clips 0 and 15 (the first and the last of the batch: the B = 2 x T = 35 test's tolerances);
+    (ii) two joint steps on a fixed batch: finite loss and gradient norm, falling loss, every parameter group moved
+    (models/gaze_grcn_cascade.py:188-445, models/base.py:278-297)."""
+    from oracle import torch_ref
+    from recurrent_gaze_prediction_amd.finetune import EndToEndCascade
+    from test_cascade_gpu import TOL, rel_err, to_t
+    B, T = 16, 35
+    free, _ = torch.cuda.mem_get_info(gpu)
+    if free < 80e9:
+        pytest.skip('needs ~60 GB of free device memory')
+    p_c = syn.cascade_params(93)
+    m = EndToEndCascade(B, T, dtype='bf16', device=gpu, seed=91, cascade_params=p_c)
+    g = torch.Generator(device=gpu)
+    g.manual_seed(92)
+    v = torch.rand(B * T, 16, 112, 112, 3, device=gpu, generator=g) - 0.5
+    fr = torch.rand(B, T, 98, 98, 3, device=gpu, generator=g)
+    gt, _ = syn.gaze_maps(94, B, T)
+    lab = torch.tensor((gt / gt.max()).astype(np.float32), device=gpu)
+    # (i) forward
+    maps = m.forward(v, fr).clone()
+    feats = m.feats.reshape(B, T, 1024, 7, 7)
+    tp = to_t(p_c)
+    old = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        with torch.no_grad():
+            for clip in (0, 15):
+                ref = torch_ref.cascade_forward(fr[clip:clip + 1].cpu().double(), feats[clip:clip + 1].cpu().double(), tp)
+                e = rel_err(maps[clip:clip + 1].cpu().numpy(), ref.numpy())
+                assert e < TOL['bf16']['maps'], 'clip %d: maps differ from the oracle by %.3e' % (clip, e)
+    finally:
+        torch.set_num_threads(old)
+    # (ii) two joint steps
+    w0, h0 = m.c3d.flat_params.clone(), m.head.flat_params.clone()
+    s0 = m.head.weights['shallownet.fc1_w'].clone()
+    losses = []
+    for _ in range(3):
+        loss, gnorm = m.train_step(v, fr, lab, lr=1e-3)
+        losses.append(float(loss))
+        assert np.isfinite(losses[-1]) and np.isfinite(float(gnorm)) and float(gnorm) > 0
+    assert losses[-1] < losses[0], losses
+    assert float((m.c3d.flat_params - w0).abs().max()) > 0 and float((m.head.flat_params - h0).abs().max()) > 0
+    assert torch.equal(m.head.weights['shallownet.fc1_w'], s0)
+    del m
+    torch.cuda.empty_cache()

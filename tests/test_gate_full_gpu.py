@@ -117,7 +117,8 @@ def test_every_layer_against_the_second_kernel_family_and_three_oracle_windows(g
     print('patch vs igemm family, worst window per layer:', {k: '%.2e' % v for k, v in report.items()})
 
 
-def test_metrics_gate_on_the_config3_workload(gpu, workload):
+@pytest.mark.parametrize('seeds', [(61, 67, 68, 69), (161, 167, 168, 169)], ids=['draw0', 'draw1'])
+def test_metrics_gate_on_the_config3_workload(gpu, workload, seeds):
     """north_star: "AUC/CC within +-1e-3 of reference" on gaze_grcn 16-frame clips.  1024 maps of the default bf16 plan
     (patch kernels, persistent ConvGRU, bf16 head) against the fp32 oracle chain, scored as models/evaluate_gaze.py
     scores them.  Cases as in test_end_to_end_metrics_gate_T16: A random-init head; B peaked maps on fixations that
@@ -128,14 +129,19 @@ def test_metrics_gate_on_the_config3_workload(gpu, workload):
     near a multiple of 0.1 flips one ROC step under ANY perturbation, and bf16 perturbs the logits by 5e-3 of their range
     (profiles/r04_gate_attribution.json: half from the bf16 conv features, half from the bf16 head, neither alone under
     1e-3 at 48 frames).  The flips are zero-mean, so their average shrinks with the number of frames scored: at this
-    workload's 1024 frames the drift is inside +-1e-3 (asserted); NSS (unbounded) within 1e-3 * max(1, |NSS|)."""
+    workload's 1024 frames the drift is inside +-1e-3 (asserted); NSS (unbounded) within 1e-3 * max(1, |NSS|).
+
+    Two independent draws of everything downstream of the conv features (head weights, gaze maps, fixations, the
+    fixations that follow the maps), so the +-1e-3 statement does not rest on one sample; the
+    1024 windows and the conv weights are the module fixture's."""
+    s_head, s_gaze, s_fix, s_follow = seeds
     from recurrent_gaze_prediction_amd.engine import GrcnEngine
     ref_feat = workload['ref'].reshape(B, T, 1024, 7, 7)
-    gt, centres = syn.gaze_maps(67, B, T)
-    fix = syn.fixation_maps(68, centres)
+    gt, centres = syn.gaze_maps(s_gaze, B, T)
+    fix = syn.fixation_maps(s_fix, centres)
     report, bad = {}, {}
     for label, out_scale in (('A', 1.0), ('BC', 40.0)):
-        hp = syn.grcn_params(61, T, gru_std=0.05, random_bn=True)
+        hp = syn.grcn_params(s_head, T, gru_std=0.05, random_bn=True)
         hp['out_W'] = hp['out_W'] * out_scale
         with torch.no_grad():
             ref = torch_ref.softmax_maps(torch_ref.grcn_forward(ref_feat, {k: torch.tensor(v) for k, v in hp.items()}))
@@ -146,7 +152,7 @@ def test_metrics_gate_on_the_config3_workload(gpu, workload):
         head.status()
         got = probs.cpu().numpy().reshape(N, 49, 49)
         assert np.isfinite(got).all()
-        cases = {'A': (gt, fix)} if label == 'A' else {'B': _fixations_following(ref, 69), 'C': (gt, fix)}
+        cases = {'A': (gt, fix)} if label == 'A' else {'B': _fixations_following(ref, s_follow), 'C': (gt, fix)}
         for name, (g_, f_) in cases.items():
             s_ref, s_got = _metric_scores(ref, g_, f_, N), _metric_scores(got, g_, f_, N)
             for metric in s_ref:
@@ -155,6 +161,6 @@ def test_metrics_gate_on_the_config3_workload(gpu, workload):
                 tol = 1e-3 * max(1.0, abs(s_ref[metric])) if metric == 'NSS' else 1e-3
                 if not abs(d) < tol:
                     bad[(name, metric)] = report[(name, metric)]
-    print('config-3 metrics gate, 1024 frames (oracle score, HIP - oracle):', report)
+    print('config-3 metrics gate, 1024 frames, seeds %s (oracle score, HIP - oracle):' % (seeds,), report)
     assert not bad, (bad, report)
     assert report[('B', 'AUC_Judd')][0] > 0.8 and report[('B', 'AUC_Borji')][0] > 0.65, report
