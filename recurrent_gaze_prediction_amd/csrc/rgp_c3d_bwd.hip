@@ -211,14 +211,14 @@ __global__ void conv1a_unpack_grad_kernel(const float* __restrict__ dw1, float* 
   grad[i] += dw1[(long long)(t2 * 16 + kx * 4 + c) * 64 + n];
 }
 
-// conv2a / conv3a / conv3b filter gradients (bf16): one block per (32 input channels, 64 output channels, column range)
+// conv2a ... conv4b filter gradients (bf16): one block per (32 input channels, 64 output channels, column range)
 template <int CIN, int COUT, int HW, int DEPTH>
-int launch_wgrad_patch(const bf16_t* x, const bf16_t* dy, float* dw, int n, hipStream_t s) {
-  using Cfg = WgpCfg<CIN, COUT, HW, DEPTH>;
+int launch_wgrad_patch(const bf16_t* x, const bf16_t* dy, float* dw, float* db, int n, hipStream_t s) {
+  using Cfg = std::conditional_t<HW == 14, Wgp14Cfg<CIN, COUT>, WgpCfg<CIN, COUT, HW, DEPTH>>;
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
   WgradPatchParams p;
-  p.x = x; p.dy = dy; p.dw = dw; p.n_windows = n;
+  p.x = x; p.dy = dy; p.dw = dw; p.db = db; p.n_windows = n;
   p.splits = std::max(8, n_cu / (Cfg::CS * Cfg::NS) / 8 * 8);          // a multiple of 8: one XCD per column range
   auto kern = wgrad_patch_bf16_kernel<CIN, COUT, HW, DEPTH>;
   RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
@@ -227,12 +227,15 @@ int launch_wgrad_patch(const bf16_t* x, const bf16_t* dy, float* dw, int n, hipS
   return RGP_OK;
 }
 
-int run_wgrad_patch(rgp_c3d* c, int layer, int n, float* dw, hipStream_t s) {
+// db != nullptr: the layer's bias gradient too (un-pooled layers; the pooled layers' comes from the un-pool kernel)
+int run_wgrad_patch(rgp_c3d* c, int layer, int n, float* dw, float* db, hipStream_t s) {
   const bf16_t* x = (const bf16_t*)(c->ws + c->act_off[layer]);
   const bf16_t* dy = (const bf16_t*)(c->ws + c->B[layer].dypre_off);
-  if (layer == 1) return launch_wgrad_patch<64, 128, 56, 16>(x, dy, dw, n, s);
-  if (layer == 2) return launch_wgrad_patch<128, 256, 28, 8>(x, dy, dw, n, s);
-  if (layer == 3) return launch_wgrad_patch<256, 256, 28, 8>(x, dy, dw, n, s);
+  if (layer == 1) return launch_wgrad_patch<64, 128, 56, 16>(x, dy, dw, db, n, s);
+  if (layer == 2) return launch_wgrad_patch<128, 256, 28, 8>(x, dy, dw, db, n, s);
+  if (layer == 3) return launch_wgrad_patch<256, 256, 28, 8>(x, dy, dw, db, n, s);
+  if (layer == 4) return launch_wgrad_patch<256, 512, 14, 4>(x, dy, dw, db, n, s);
+  if (layer == 5) return launch_wgrad_patch<512, 512, 14, 4>(x, dy, dw, db, n, s);
   return set_err(RGP_EINVAL, "wgrad_patch: no kernel for layer %d", layer);
 }
 
@@ -302,9 +305,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         RGP_TRY((launch_wgrad<T, G0>(p, s)));
         conv1a_unpack_grad_kernel<<<(27 * 3 * 64 + 255) / 256, 256, 0, s>>>(p.dW, grads + b.grad_w);
         RGP_HIP(hipGetLastError());
-      } else if (sizeof(T) == 2 && c->use_patch() && i >= 1 && i <= 3 && ((dev_knob("RGP_WGPATCH", 7) >> (i - 1)) & 1)) {
+      } else if (sizeof(T) == 2 && c->use_patch() && i >= 1 && i <= 5 && ((dev_knob("RGP_WGPATCH", 31) >> (i - 1)) & 1)) {
         // wgrad_patch.hip.h: conv2a 5.2 -> 4.0 ms, conv3a 2.3 -> 2.3, conv3b 4.8 -> 4.3 ms per 256 windows against
-        // wgrad_kernel (dev builds: one mask bit per layer)
+        // wgrad_kernel (dev builds: one mask bit per layer); round 5: conv4a / conv4b on its window-pair form
         RGP_TRY(run_wgrad_patch(c, i, n, grads + b.grad_w, s));
       } else {
         p.dW = grads + b.grad_w;

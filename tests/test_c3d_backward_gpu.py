@@ -132,8 +132,10 @@ def test_c3d_backward_operators(gpu, case, autograd, dtype, kernels):
 
 
 def test_patch_filter_gradients_odd_window_count(gpu):
-    """wgrad_patch.hip.h (conv2a, conv3a, conv3b; bf16): 5 windows give column ranges of unequal length per block
-    (35 / 70 columns over 8 / 64 ranges), empty ranges, and several seamless column changes per block."""
+    """wgrad_patch.hip.h (conv2a ... conv4b; bf16): 5 windows give column ranges of unequal length per block
+    (35 / 70 columns over 8 / 64 ranges), empty ranges, and several seamless column changes per block; on the 14 x 14
+    layers (conv4a, conv4b: a column = a PAIR of windows) 3 columns of which the last holds a single window, i.e. the
+    missing-window path and an odd number of groups per block."""
     from recurrent_gaze_prediction_amd.engine import C3DEngine
     n = 5
     p = syn.c3d_params(33)
@@ -148,7 +150,7 @@ def test_patch_filter_gradients_odd_window_count(gpu):
     old = torch.get_num_threads()
     torch.set_num_threads(16)
     try:
-        for i in (1, 2, 3):
+        for i in (1, 2, 3, 4, 5):
             name = NAMES[i]
             x = ncdhw(eng.read_layer(i - 1, n).cpu().reshape((n,) + tuple(int(v) for v in torch_ref_out_shape(i - 1))))
             dy = ncdhw(eng.read_grad_image(i, n).cpu())
@@ -164,8 +166,9 @@ def test_filter_gradients_at_bench_scale(gpu):
     """wgrad_patch.hip.h at a window count where its column-range partition, XCD placement and 8-slot plane ring do what
     they do in the fine-tune benchmark: 67 windows (odd), replicas of 2 distinct windows with the same upstream gradient.
     Windows are independent, so dW = 34 dW(w0) + 33 dW(w1) with each term from torch.nn.grad.conv3d_weight on the
-    operands the device holds for windows 0 and 1 -- every block of the launch works on real, non-zero data.  conv2a,
-    conv3a, conv3b (patch kernels) and conv4a..conv5b (wgrad_kernel at this scale); then the same check for the second
+    operands the device holds for windows 0 and 1 -- every block of the launch works on real, non-zero data.  conv2a ...
+    conv4b (patch kernels; conv4a / conv4b: 34 window pairs, the last one half empty) and conv5a / conv5b (wgrad_kernel);
+    then the same check for the second
     kernel family (wgrad_kernel on every layer), each against the operands ITS OWN forward / backward chain left on the
     device (the two chains differ by ReLU-gate and pooling-route flips, so their gradients are not compared with each other)."""
     from recurrent_gaze_prediction_amd.engine import C3DEngine

@@ -115,10 +115,12 @@ def test_top_bucket_release_follows_the_co_residency_rule(gpu):
     side = torch.cuda.Stream(gpu)
     copies = []
     with torch.cuda.stream(side):
-        for bucket, ready in eng.grad_buckets():
+        for bucket, ready in eng.grad_buckets():       # completion order (TOP, GRU, PROJ), not the flat buffer's order
             ready(side)
-            copies.append(bucket.clone())
+            copies.append((bucket, bucket.clone()))
     torch.cuda.current_stream(gpu).wait_stream(side)
     torch.cuda.synchronize()
     eng.status()
-    assert torch.equal(torch.cat(copies), eng.flat_grads) and bool(torch.isfinite(eng.flat_grads).all())
+    assert sum(b.numel() for b, _ in copies) == eng.flat_grads.numel()
+    for bucket, copy in copies:                         # what the side stream saw behind `ready` is the final gradient
+        assert torch.equal(bucket, copy) and bool(torch.isfinite(copy).all()) and float(copy.abs().max()) > 0
