@@ -256,7 +256,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     const C3dLayerSpec& l = kLayers[i];
     const C3dBwdLayer& b = c->B[i];
     const int Mw = l.D * l.H * l.H;
-    if (!pooled(i)) {  // bias gradient (pooled layers: done by unpool below)
+    // filter gradient on the patch kernels (wgrad_patch.hip.h; dev builds: one mask bit per layer)?
+    const bool wg_patch = sizeof(T) == 2 && c->use_patch() && i >= 1 && i <= 5 && ((dev_knob("RGP_WGPATCH", 31) >> (i - 1)) & 1);
+    if (!pooled(i) && !wg_patch) {  // bias gradient (pooled layers: done by unpool below; patch kernels: with the filter gradient)
       const long long rows = (long long)n * Mw;
       colsum_kernel<T><<<std::min(blocks_for(rows, 256 / (l.cout / 8) * 16), 1024), 256, 0, s>>>(      // (every block ends with C atomics)
           
@@ -305,10 +307,11 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
         RGP_TRY((launch_wgrad<T, G0>(p, s)));
         conv1a_unpack_grad_kernel<<<(27 * 3 * 64 + 255) / 256, 256, 0, s>>>(p.dW, grads + b.grad_w);
         RGP_HIP(hipGetLastError());
-      } else if (sizeof(T) == 2 && c->use_patch() && i >= 1 && i <= 5 && ((dev_knob("RGP_WGPATCH", 31) >> (i - 1)) & 1)) {
+      } else if (wg_patch) {
         // wgrad_patch.hip.h: conv2a 5.2 -> 4.0 ms, conv3a 2.3 -> 2.3, conv3b 4.8 -> 4.3 ms per 256 windows against
-        // wgrad_kernel (dev builds: one mask bit per layer); round 5: conv4a / conv4b on its window-pair form
-        RGP_TRY(run_wgrad_patch(c, i, n, grads + b.grad_w, s));
+        // wgrad_kernel; round 5: conv4a / conv4b on its window-pair form, and the un-pooled layers' bias gradient
+        // (conv3a, conv4a) on the kernel's spare MFMA slot instead of a colsum pass over the gradient image
+        RGP_TRY(run_wgrad_patch(c, i, n, grads + b.grad_w, pooled(i) ? nullptr : grads + b.grad_b, s));
       } else {
         p.dW = grads + b.grad_w;
         RGP_TRY((launch_wgrad<T, 1>(p, s)));

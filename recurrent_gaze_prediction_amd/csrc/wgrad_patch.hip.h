@@ -344,6 +344,14 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(f.bl[j]), "+v"(f.bh[j]));
 #pragma unroll
     for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(f.al[i]), "+v"(f.ah[i]));
+    // the bias unit's A fragment is all ones (bf16): acc[6][j] = column sums of dY.  Written HERE, 24 MFMAs ahead of its
+    // use: the MFMAs are inline asm, so the compiler pads no VALU-write -> MFMA-read hazard for them (a select placed
+    // directly in front of the unit's first MFMA made that MFMA read the old registers)
+    if (bias_unit) {
+      f.al[6] = (i32x2_wg){0x3F803F80, 0x3F803F80};
+      f.ah[6] = (i32x2_wg){0x3F803F80, 0x3F803F80};
+    }
+    asm volatile("" : "+v"(f.al[6]), "+v"(f.ah[6]));
   };
   // the 28 MFMAs of a step on `cur`, with the 22 fragment reads of step S (of this group, or step 0 of the next one)
   // into `nxt` issued one behind each of the first 22: the wave never stops feeding the matrix pipe to issue reads
@@ -355,8 +363,7 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
     for (int j = 0; j < 4; ++j) b[j] = (i32x4_wg){cur.bl[j][0], cur.bl[j][1], cur.bh[j][0], cur.bh[j][1]};
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      i32x4_wg a = (i32x4_wg){cur.al[i][0], cur.al[i][1], cur.ah[i][0], cur.ah[i][1]};
-      if (i == 6 && bias_unit) a = (i32x4_wg){0x3F803F80, 0x3F803F80, 0x3F803F80, 0x3F803F80};      // bf16 ones: acc[6][j] = column sums of dY
+      const i32x4_wg a = (i32x4_wg){cur.al[i][0], cur.al[i][1], cur.ah[i][0], cur.ah[i][1]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         wgp_mfma(acc[i][j], a, b[j]);
