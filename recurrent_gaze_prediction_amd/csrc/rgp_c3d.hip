@@ -103,11 +103,15 @@ int forward_chunk(rgp_c3d* c, const float* video, const FrameSrc* fs, int n, flo
 
 template <typename T>
 int set_weights_impl(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
+  // one launch for the eight packs (a training step re-packs after every optimizer update: as eight launches of 5 - 30 us
+  // each they ran one after the other, none of them filling the chip)
+  PackBatch<T> pk(c->ws, s);
   for (int i = 0; i < 8; ++i) {
     // (no memset: the packed area is zero from bind time outside the positions the pack writes)
-    RGP_TRY(pack_filter<T>(c->L[i], w->w[i], c->ws, kLayers[i].cout, 0, s));
+    RGP_TRY(pk.add(c->L[i], w->w[i], kLayers[i].cout, 0));
     c->bias[i] = w->b[i];
   }
+  RGP_TRY(pk.flush());
   c->weights_set = true;
   return RGP_OK;
 }

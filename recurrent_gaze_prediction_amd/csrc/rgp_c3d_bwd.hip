@@ -444,13 +444,15 @@ int c3d_bwd_upload(rgp_c3d* c, hipStream_t s) {
   return RGP_OK;
 }
 
+template <typename T>
+static int c3d_bwd_pack_t(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
+  PackBatch<T> pk(c->ws, s);                       // the seven rotated input-gradient filters in one launch
+  for (int i = 1; i < 8; ++i) RGP_TRY(pk.add(c->B[i].dg, w->w[i], kLayers[i].cin, 0));
+  return pk.flush();
+}
+
 int c3d_bwd_pack(rgp_c3d* c, const rgp_c3d_weights* w, hipStream_t s) {
-  for (int i = 1; i < 8; ++i) {
-    const ConvDesc& d = c->B[i].dg;
-    if (c->dtype == RGP_BF16) RGP_TRY(pack_filter<bf16_t>(d, w->w[i], c->ws, kLayers[i].cin, 0, s));
-    else RGP_TRY(pack_filter<float>(d, w->w[i], c->ws, kLayers[i].cin, 0, s));
-  }
-  return RGP_OK;
+  return c->dtype == RGP_BF16 ? c3d_bwd_pack_t<bf16_t>(c, w, s) : c3d_bwd_pack_t<float>(c, w, s);
 }
 
 extern "C" {
