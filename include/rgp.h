@@ -403,10 +403,14 @@ int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int flags);
  *                             kernel instead of the layer-specific patch kernels -- the library's second, independent
  *                             implementation of those layers (tile chosen by problem size: 256x256 / 512x128 /
  *                             staggered 256x128 / 128x128), kept for cross-checking the default path.
- *  RGP_C3D_KERNELS_TILE128    with RGP_C3D_KERNELS_IGEMM: every implicit GEMM of the plan on the 128x128 tile loop. */
+ *  RGP_C3D_KERNELS_TILE128    with RGP_C3D_KERNELS_IGEMM: every implicit GEMM of the plan on the 128x128 tile loop.
+ *  RGP_C3D_CONV2A_ROWWISE     inference plans on the patch kernels: conv2a + pool2 through the row-wise fetch of
+ *                             conv_patch.hip.h (what training plans run) instead of the plane-slab fetch of
+ *                             conv_patch_slab.hip.h; bit-identical results (a cross-check and A/B switch). */
 #define RGP_C3D_SAVE_FOR_BACKWARD 1
 #define RGP_C3D_KERNELS_IGEMM 2
 #define RGP_C3D_KERNELS_TILE128 4
+#define RGP_C3D_CONV2A_ROWWISE 8
 /* Name of the kernel instantiation the plan launches for layer i's forward at n_windows windows ("" if unknown):
  * what a profiler shows for the stage rgp_c3d_profile_read times as index i. */
 const char* rgp_c3d_layer_kernel_name(const rgp_c3d_t* plan, int layer, int n_windows);

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librgp_hip.
 RGP_F32, RGP_BF16 = 0, 1
 RGP_ETIMEOUT = -5
 RGP_GRCN_SAVE_FOR_BACKWARD, RGP_GRCN_PER_STEP, RGP_GRCN_UNFOLDED_HEAD = 1, 2, 4
-RGP_C3D_SAVE_FOR_BACKWARD, RGP_C3D_KERNELS_IGEMM, RGP_C3D_KERNELS_TILE128 = 1, 2, 4
+RGP_C3D_SAVE_FOR_BACKWARD, RGP_C3D_KERNELS_IGEMM, RGP_C3D_KERNELS_TILE128, RGP_C3D_CONV2A_ROWWISE = 1, 2, 4, 8
 RGP_FAULT_SEQ_LOST_MEMBER, RGP_FAULT_BPTT_LOST_MEMBER = 1, 2
 RGP_GRCN_GRADS_TOP, RGP_GRCN_GRADS_GRU, RGP_GRCN_GRADS_PROJ = 0, 1, 2
 RGP_SQNORM_PARTIALS = 256          # include/rgp.h

@@ -11,16 +11,17 @@
 // rows incl. the x halo) brought in by 3 LDS-DMA instructions per wave; fragments of 2 adjacent pooling windows x
 // (dz, dy, dx) on a row pitch of 58 * 64 = 128 (mod 256) bytes, plane buffers at 32 (k & 1) (mod 256): every 16-lane
 // group of a ds_read_b128 covers the 64 banks once, no swizzle.  Everything else (K order, filter ring, plane ring,
-// staggered wave groups, pooled epilogue, arg-max codes, the last-touch nt hint) as described in conv_patch.hip.h; the
-// packed filter and the activation layouts are the same, so the two kernels are interchangeable per launch
-// (rgp_conv_patch.hip picks by RGP_C2A_SLAB; results are bit-identical: the K order and the accumulation order inside a
-// lane are the same).
+// staggered wave groups, pooled epilogue, the last-touch nt hint) as described in conv_patch.hip.h; the packed filter and
+// the activation layouts are the same, so the two kernels are interchangeable per launch: inference plans take this one
+// unless created with RGP_C3D_CONV2A_ROWWISE, and the results are bit-identical (the K order and the accumulation order
+// inside a lane are the same; tests/test_c3d_gpu.py compares the two plans with torch.equal).  Same-box A/B, round 5
+// (profiles/r05_ab_conv2a_slab.txt): conv2a 14.23 vs 14.35 - 14.45 ms per 1024 windows (-0.9 ... -1.5 %).
 #pragma once
 #include "conv_patch.hip.h"
 
 namespace rgp {
 
-template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchSlabCfg {
+template <int CIN, int NOUT, int HW, int DEPTH> struct PatchSlabCfg {
   static constexpr int WP = HW + 2;                       // padded row: 58 / 30 pixels
   static constexpr int XPN = HW / 2;                      // pooling windows per pooled row: 28 / 14
   static constexpr int NCC = CIN / 32;                    // channel sweeps: 2 / 8
@@ -30,8 +31,7 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchSl
   static constexpr int PLANE_PIX = PPW * 128;             // pixels fetched per slab: 384 / 256 (348 / 180 used)
   static constexpr int PLANE_BYTES = PLANE_PIX * 64, PLANE_STRIDE = PLANE_BYTES + 256;
   static constexpr int BRING_OFF = (3 * PLANE_STRIDE + 32 + PLANE_BYTES + 1023) / 1024 * 1024;
-  static constexpr int NI = NOUT / (16 * WNW);            // 16-column MFMA tiles per wave: 4 (2 for the 64 / 128-channel
-                                                          // input gradients of conv2a / conv3a: wave tile 112 x 32)
+  static constexpr int NI = NOUT / (16 * WNW);            // 16-column MFMA tiles per wave: 4
   static constexpr int BPW = (NOUT + 127) / 128;          // filter-slab DMA instructions per wave and step: 1 / 2
   static constexpr int BSLOT = BPW * 128 * 64;            // 8 / 16 KB: filter rows (padded to 128: the packing pads too) x 32 K elements
   static constexpr int NSLOT = 4, AHEAD = 3;
@@ -40,39 +40,29 @@ template <int CIN, int NOUT, int HW, int DEPTH, bool POOL = true> struct PatchSl
   // its own (the filter ring keeps running across tiles)
   static constexpr int STG_LD = NOUT + 8;
   static constexpr int STGA_OFF = STG_OFF + WIN * STG_LD * 2;
-  static constexpr int SMEM = POOL ? STGA_OFF + WIN * STG_LD : STG_OFF;     // 154 944 / 154 272 (pooled layers)
+  static constexpr int SMEM = STGA_OFF;                   // (no arg-max codes: inference plans only)
   static constexpr int NSTEP = NCC * 27;
   static constexpr int YT = HW / 4;                       // tiles per pooled plane
   static constexpr int TILES_PER_WINDOW = (DEPTH / 2) * YT;
   static constexpr int K = 27 * CIN;
   static constexpr int IN_ROW = WP * CIN, IN_PLANE = WP * IN_ROW, IN_IMG = (DEPTH + 2) * IN_PLANE;      // elements
-  static constexpr int OW = POOL ? HW / 2 : HW, OD = POOL ? DEPTH / 2 : DEPTH;   // output extent
+  static constexpr int OW = HW / 2, OD = DEPTH / 2;       // output extent (pooled)
   static constexpr int OUT_ROW = (OW + 2) * NOUT, OUT_PLANE = (OW + 2) * OUT_ROW, OUT_IMG = (OD + 2) * OUT_PLANE;
   static constexpr int CGN = NOUT / 8;                    // epilogue: 8-channel groups
-  static_assert(WNW * 16 * NI == NOUT && (NI == 4 || (NI == 2 && !POOL)) && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0,
-                "tile shape");
+  static_assert(WNW * 16 * NI == NOUT && NI == 4 && WMW * 14 == WIN && XPN % 2 == 0 && HW % 4 == 0 && CIN % 32 == 0, "tile shape");
   static_assert((WP * 64) % 256 == 128, "row pitch = 128 (mod 256): the bank argument of the header");
   static_assert(SMEM <= 160 * 1024, "LDS budget");
-  static_assert(!POOL || WIN * CGN == 2 * 448, "pooled epilogue: two items per thread (448 of the 512 threads)");
+  static_assert(WIN * CGN == 2 * 448, "pooled epilogue: two items per thread (448 of the 512 threads)");
   static_assert((STG_LD * 2) % 16 == 0 && STG_LD % 8 == 0, "staging rows keep 16- / 8-byte alignment");
 };
 
-// In every variant MFMA column 16 j + c of a wave carries channel 64 wn + 4 c + j (the filter slab is fetched in that row
-// order), so a lane holds 4 adjacent channels of a position.
-// POOL: 2x2x2 max-pool epilogue (conv2a, conv3b): the lane's four pooled channels of a window are staged with one 8-byte
-// LDS write (their arg-max codes with one 4-byte write; four 2-byte writes each before: conv2a -1.5 %).
-// !POOL (conv3a): the same tiles -- the row order (2x2x2 blocks of positions) is immaterial to a convolution -- stored
-// un-pooled: 8 bytes straight from registers, 16 lanes = 128 contiguous bytes.
-// DGRAD (!POOL): the same convolution as the input gradient of a layer (in = dY before pooling, halo-padded; filter =
-// the rotated, in/out-swapped one of the backward plan): no bias, no ReLU, the result masked by the forward activation.
-// DENSE (DGRAD only): the output is the dense, un-masked [n][D*HW*HW][NOUT] image the un-pool kernel consumes (gradient
-// w.r.t. a pooled layer's output).
-template <int CIN, int NOUT, int HW, int DEPTH, bool POOL, bool ARGMAX = false, bool DGRAD = false, bool DENSE = false>
+// MFMA column 16 j + c of a wave carries channel 64 wn + 4 c + j (the filter slab is fetched in that row order), so a lane
+// holds 4 adjacent channels of a position; 2x2x2 max-pool epilogue: the lane's four pooled channels of a window are staged
+// with one 8-byte LDS write.  Inference plans only: no arg-max codes, no input-gradient or un-pooled variants (those are
+// conv_patch.hip.h's; round 4 carried them here too, never instantiated).
+template <int CIN, int NOUT, int HW, int DEPTH>
 static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const ConvPatchParams p) {
-  static_assert(!DENSE || DGRAD, "dense output: input gradients only");
-  static_assert(POOL || !ARGMAX, "arg-max codes belong to the pooled layers");
-  static_assert(!POOL || !DGRAD, "the input gradient is an un-pooled convolution");
-  using C = PatchSlabCfg<CIN, NOUT, HW, DEPTH, POOL>;
+  using C = PatchSlabCfg<CIN, NOUT, HW, DEPTH>;
   constexpr int NI = C::NI;
   extern __shared__ __attribute__((aligned(16))) char cp_smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cp_smem;
@@ -133,8 +123,8 @@ static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const 
   // igemm_wide.hip.h (physical chunk c of row r holds logical chunk c ^ ((-(r >> 2)) & 3))
   const int brow = lane >> 2;
   const int bchk = (lane & 3) ^ ((-(brow >> 2)) & 3);
-  // filter row (output channel) behind row brow of 1-KB block blk: blk * 16 + brow, or (!POOL) wave blk / NI, column
-  // tile blk % NI: channel 16 NI (blk / NI) + NI brow + blk % NI (rows >= NOUT of a 64-channel filter are the packing's zeros)
+  // filter row (output channel) behind row brow of 1-KB block blk: wave blk / NI, column tile blk % NI: channel
+  // 16 NI (blk / NI) + NI brow + blk % NI
   auto b_row = [&](int blk) { return (blk / NI) * (16 * NI) + brow * NI + (blk % NI); };
   const char* b_src[C::BPW];
 #pragma unroll
@@ -164,7 +154,7 @@ static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const 
   const int cg = tid % C::CGN;                                // POOL epilogue, store pass: this thread's 8 output channels
   float b4[NI];                                               // bias of this lane's NI MFMA columns
 #pragma unroll
-  for (int q = 0; q < NI; ++q) b4[q] = DGRAD ? 0.f : p.bias[wn * (16 * NI) + frow * NI + q];
+  for (int q = 0; q < NI; ++q) b4[q] = p.bias[wn * (16 * NI) + frow * NI + q];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue (once): planes 0, 1 of the first sweep, filter slabs of steps 0 .. 2.  Afterwards the filter ring and
   // the plane prefetch run across tile boundaries: step s of a tile issues slab s + 3 (mod NSTEP) and the last sweep of
@@ -288,7 +278,7 @@ static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const 
       // last touch of them.  Those fetches carry the `nt` hint (the line becomes the first candidate for eviction), which
       // leaves more of the L2 to the filter and to the neighbouring tiles' rows: conv2a -3.5 %, conv3b -0.5 %; conv3a
       // (CIN = 128) measured +0.5 % and the input gradients were not measured: both stay without it.
-      constexpr bool LT = !DGRAD && CIN != 128;
+      constexpr bool LT = CIN != 128;
       tap_group(I2{}, cc, 0, plane_src(tile, cc, 2), 2, plane_src(tile, cc, 3), 3, LT && (cc & 1) != 0);
       tap_group(I1{}, cc, 1, plane_src(ntile, ncc, 0), 0, nullptr, 0, LT && (ncc & 1) != 0);
       tap_group(I1{}, cc, 2, plane_src(ntile, ncc, 1), 1, nullptr, 0, LT && (ncc & 1) != 0);
@@ -302,36 +292,19 @@ static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const 
       for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
-    } else if constexpr (POOL) {
+    } else {
       // ---- epilogue: pool in registers (a lane holds the 4 members of a window with its dz, lane ^ 16 the other 4),
-      // bias + ReLU, pooled bf16 tile (and arg-max codes) through LDS, 16-byte (8-byte) stores ----
+      // bias + ReLU, pooled bf16 tile through LDS, 16-byte stores ----
       bf16_t* stg = (bf16_t*)(cp_smem + C::STG_OFF);
-      unsigned char* stga = (unsigned char*)(cp_smem + C::STGA_OFF);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        // MFMA column frow of n-tile j carries channel 64 wn + 4 frow + j (b_row): the lane's four pooled values of a
-        // window are adjacent channels -- one 8-byte LDS write (one 4-byte write of codes) instead of four 2-byte ones
         unsigned short pv[4];
-        unsigned pc = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 c = acc[i][j];
-          if constexpr (ARGMAX) {
-            float best = c[0];
-            int idx = 0;
-            if (c[1] > best) { best = c[1]; idx = 1; }
-            if (c[2] > best) { best = c[2]; idx = 2; }
-            if (c[3] > best) { best = c[3]; idx = 3; }
-            const float ob = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, best), 0x401F));   // lane ^ 16
-            const int oi = __builtin_amdgcn_ds_swizzle(idx, 0x401F);
-            // this lane: dz = 0 (members 0 .. 3), the other: dz = 1
-            pv[j] = f2bf(fmaxf((ob > best ? ob : best) + b4[j], 0.f));
-            pc |= (unsigned)(ob > best ? oi + 4 : idx) << (8 * j);
-          } else {
-            const float x = cp_max(cp_max3(c[0], c[1], c[2]), c[3]);
-            const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
-            pv[j] = f2bf(cp_relu(cp_max(x, y) + b4[j]));
-          }
+          const float x = cp_max(cp_max3(c[0], c[1], c[2]), c[3]);
+          const float y = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));   // lane ^ 16
+          pv[j] = f2bf(cp_relu(cp_max(x, y) + b4[j]));
         }
         if ((fk & 1) == 0) {
           const int so = (2 * (7 * wm + i) + (fk >> 1)) * C::STG_LD + wn * 64 + 4 * frow;
@@ -339,57 +312,17 @@ static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const 
           o.x = (unsigned)pv[0] | ((unsigned)pv[1] << 16);
           o.y = (unsigned)pv[2] | ((unsigned)pv[3] << 16);
           *(uint2*)(stg + so) = o;
-          if constexpr (ARGMAX) *(unsigned*)(stga + so) = pc;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // raw barrier: __syncthreads() would also drain the look-ahead DMA
       __builtin_amdgcn_s_barrier();
       bf16_t* obase = p.out + (long long)tn * C::OUT_IMG + (zp + 1) * C::OUT_PLANE + (2 * yp + 1) * C::OUT_ROW + NOUT;
-      unsigned char* abase = ARGMAX ? p.argmax + (((long long)tn * (DEPTH / 2) + zp) * (HW / 2) + 2 * yp) * (long long)((HW / 2) * NOUT) : nullptr;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int w = tid / C::CGN + (512 / C::CGN) * k;      // pooling window of the tile
         if (w < C::WIN && !RGP_CP_ABL(p, 4)) {
           const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
           *(u32x4*)(obase + ypl * C::OUT_ROW + xp * NOUT + cg * 8) = *(const u32x4*)(stg + w * C::STG_LD + cg * 8);
-          if constexpr (ARGMAX) *(uint2*)(abase + (ypl * (HW / 2) + xp) * NOUT + cg * 8) = *(const uint2*)(stga + w * C::STG_LD + cg * 8);
-        }
-      }
-    } else {
-      // ---- epilogue: bias + ReLU, 8-byte stores from registers.  Register e of accumulator (i, j): row 4 fk + e of
-      // m-tile i = window 2 (7 wm + i) + (fk >> 1), dz = fk & 1, dy = e >> 1, dx = e & 1; channel 64 wn + 4 frow + j ----
-      // position of (window w, dz, dy, dx): halo-padded image, or (DENSE) natural (z, y, x) order without halo
-      constexpr int ROWS = DENSE ? HW * NOUT : C::OUT_ROW, PLANES = DENSE ? HW * ROWS : C::OUT_PLANE;
-      constexpr long long IMG = DENSE ? (long long)DEPTH * PLANES : (long long)C::OUT_IMG;
-      constexpr int H1 = DENSE ? 0 : 1;
-      const long long obase = (long long)tn * IMG + (2 * zp + H1 + (fk & 1)) * PLANES + (4 * yp + H1) * ROWS + H1 * NOUT + wn * (16 * NI) + frow * NI;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int w = 2 * (7 * wm + i) + (fk >> 1);
-        const int ypl = w / C::XPN, xp = w - ypl * C::XPN;
-        const long long ow = obase + (2 * ypl) * ROWS + (2 * xp) * NOUT;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const long long oe = ow + (e >> 1) * ROWS + (e & 1) * NOUT;
-          float v[NI];
-#pragma unroll
-          for (int j = 0; j < NI; ++j) v[j] = DGRAD ? acc[i][j][e] : fmaxf(acc[i][j][e] + b4[j], 0.f);
-          if constexpr (DGRAD && !DENSE) {
-            unsigned m[NI / 2];
-            if constexpr (NI == 4) { const uint2 mm = *(const uint2*)(p.mask + oe); m[0] = mm.x; m[1] = mm.y; }
-            else m[0] = *(const unsigned*)(p.mask + oe);
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-              if (!(bf2f((bf16_t)((m[j >> 1] >> (16 * (j & 1))) & 0xffffu)) > 0.f)) v[j] = 0.f;
-          }
-          if constexpr (NI == 4) {
-            uint2 o;
-            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-            *(uint2*)(p.out + oe) = o;
-          } else {
-            *(unsigned*)(p.out + oe) = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          }
         }
       }
     }

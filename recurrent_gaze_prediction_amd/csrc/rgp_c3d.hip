@@ -124,7 +124,8 @@ int rgp_c3d_create(rgp_c3d_t** plan, int max_windows, int dtype) { return rgp_c3
 
 int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int flags) {
   RGP_REQUIRE(plan && max_windows > 0, "rgp_c3d_create: bad arguments");
-  RGP_REQUIRE((flags & ~(RGP_C3D_SAVE_FOR_BACKWARD | RGP_C3D_KERNELS_IGEMM | RGP_C3D_KERNELS_TILE128)) == 0, "rgp_c3d_create_ex: unknown flags 0x%x", flags);
+  RGP_REQUIRE((flags & ~(RGP_C3D_SAVE_FOR_BACKWARD | RGP_C3D_KERNELS_IGEMM | RGP_C3D_KERNELS_TILE128 | RGP_C3D_CONV2A_ROWWISE)) == 0,
+              "rgp_c3d_create_ex: unknown flags 0x%x", flags);
   RGP_REQUIRE(!(flags & RGP_C3D_KERNELS_TILE128) || (flags & RGP_C3D_KERNELS_IGEMM), "rgp_c3d_create_ex: RGP_C3D_KERNELS_TILE128 needs RGP_C3D_KERNELS_IGEMM");
   const int save_for_backward = flags & RGP_C3D_SAVE_FOR_BACKWARD;
   RGP_REQUIRE(dtype == RGP_F32 || dtype == RGP_BF16, "rgp_c3d_create: dtype %d", dtype);
@@ -133,7 +134,7 @@ int rgp_c3d_create_ex(rgp_c3d_t** plan, int max_windows, int dtype, int flags) {
   c->max_windows = max_windows;
   c->dtype = dtype;
   c->save = save_for_backward != 0;
-  c->kernels = flags & (RGP_C3D_KERNELS_IGEMM | RGP_C3D_KERNELS_TILE128);
+  c->kernels = flags & (RGP_C3D_KERNELS_IGEMM | RGP_C3D_KERNELS_TILE128 | RGP_C3D_CONV2A_ROWWISE);
   bool ok = true;
   Arena a;
   for (int i = 0; i < 8; ++i) {

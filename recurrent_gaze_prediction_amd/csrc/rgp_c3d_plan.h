@@ -33,9 +33,10 @@ struct rgp_c3d {
   bool use_patch() const { return dtype == RGP_BF16 && !(kernels & RGP_C3D_KERNELS_IGEMM); }
   bool tile128() const { return (kernels & RGP_C3D_KERNELS_TILE128) != 0; }
   // conv2a's INFERENCE forward on the plane-slab variant of the patch kernel (conv_patch_slab.hip.h) instead of the row-wise
-  // one (conv_patch.hip.h): same operands, bit-identical results; chosen by a same-box A/B.  Training
-  // plans (arg-max codes recorded) stay on the row-wise kernel: the slab variant's training forward measured 4 % slower.
-  bool conv2a_slab() const { return use_patch() && !save && rgp::dev_knob("RGP_C2A_SLAB", 1) != 0; }
+  // one (conv_patch.hip.h): same operands, bit-identical results; chosen by a same-box A/B and
+  // switched off per plan by RGP_C3D_CONV2A_ROWWISE.  Training plans (arg-max codes recorded) stay on the row-wise kernel:
+  // the slab variant's training forward measured 4 % slower.
+  bool conv2a_slab() const { return use_patch() && !save && !(kernels & RGP_C3D_CONV2A_ROWWISE) && rgp::dev_knob("RGP_C2A_SLAB", 1) != 0; }
   rgp::ConvDesc L[8];
   size_t act_off[9] = {0};       // act[i] = halo-padded input of layer i; act[8] = conv5b rows
   long long act_stride[9] = {0}; // elements per window

@@ -31,22 +31,21 @@ static int run_conv_patch(rgp_c3d* c, int layer, int n, hipStream_t s) {
   return RGP_OK;
 }
 
-// conv2a + pool2 on the plane-slab variant (conv_patch_slab.hip.h)
-template <bool ARGMAX>
+// conv2a + pool2 on the plane-slab variant (conv_patch_slab.hip.h): inference plans
 static int run_conv2a_slab(rgp_c3d* c, int n, hipStream_t s) {
-  using Cfg = PatchSlabCfg<64, 128, 56, 16, true>;
+  using Cfg = PatchSlabCfg<64, 128, 56, 16>;
   ConvPatchParams p;
   p.in = (const bf16_t*)(c->ws + c->act_off[1]);
   p.wp = (const bf16_t*)(c->ws + c->L[1].w_off);
   p.bias = c->bias[1];
   p.out = (bf16_t*)(c->ws + c->act_off[2]);
-  p.argmax = ARGMAX ? (unsigned char*)(c->ws + c->B[1].argmax_off) : nullptr;
+  p.argmax = nullptr;
   p.mask = nullptr;
   p.n_windows = n;
   p.ablate = dev_knob("RGP_CP_ABLATE", 0);
   int n_cu = 0;
   RGP_TRY(device_cu_count(&n_cu));
-  auto kern = conv_patch_slab_bf16_kernel<64, 128, 56, 16, true, ARGMAX>;
+  auto kern = conv_patch_slab_bf16_kernel<64, 128, 56, 16>;
   RGP_TRY(ensure_dyn_smem((const void*)kern, Cfg::SMEM));
   kern<<<n_cu, 512, Cfg::SMEM, s>>>(p);
   RGP_HIP(hipGetLastError());
@@ -100,7 +99,7 @@ int run_conv_patch_bf16(rgp_c3d* c, int layer, int n, hipStream_t s) {
   if (layer == 7) return run_conv_patch7<1>(c, layer, n, s);
   if (layer == 4) return run_conv_patch14<256, false, false>(c, layer, n, s);
   if (layer == 5) return c->save ? run_conv_patch14<512, true, true>(c, layer, n, s) : run_conv_patch14<512, true, false>(c, layer, n, s);
-  if (layer == 1 && c->conv2a_slab()) return run_conv2a_slab<false>(c, n, s);
+  if (layer == 1 && c->conv2a_slab()) return run_conv2a_slab(c, n, s);
   if (layer == 1) return c->save ? run_conv_patch<64, 128, 56, 16, true, true>(c, layer, n, s) : run_conv_patch<64, 128, 56, 16, true, false>(c, layer, n, s);
   if (layer == 2) return run_conv_patch<128, 256, 28, 8, false, false>(c, layer, n, s);
   if (layer == 3) return c->save ? run_conv_patch<256, 256, 28, 8, true, true>(c, layer, n, s) : run_conv_patch<256, 256, 28, 8, true, false>(c, layer, n, s);

@@ -679,12 +679,15 @@ class C3DEngine(object):
     """C3D conv1a..conv5b (prototxt:22-342) for up to max_windows windows per launch chain."""
 
     KERNELS = {'patch': 0, 'igemm': _lib.RGP_C3D_KERNELS_IGEMM,
-               'igemm128': _lib.RGP_C3D_KERNELS_IGEMM | _lib.RGP_C3D_KERNELS_TILE128}
+               'igemm128': _lib.RGP_C3D_KERNELS_IGEMM | _lib.RGP_C3D_KERNELS_TILE128,
+               'patch-rowwise': _lib.RGP_C3D_CONV2A_ROWWISE}
 
     def __init__(self, max_windows, dtype='bf16', device='cuda:0', save_for_backward=False, kernels='patch'):
         """kernels: 'patch' (default: the layer-specific kernels for conv2a..conv4b), 'igemm' (the general
         implicit-GEMM / filter-gradient kernels for every layer, tile by problem size) or 'igemm128' (the same on
-        the 128x128 tile loop only) -- rgp_c3d_create_ex flags; the second family exists for cross-checks."""
+        the 128x128 tile loop only), 'patch-rowwise' (the patch kernels with conv2a's inference forward on the row-wise
+        fetch instead of the plane-slab one: RGP_C3D_CONV2A_ROWWISE) -- rgp_c3d_create_ex flags; the alternatives exist
+        for cross-checks."""
         self.lib = _lib.load()
         self.device = _require_gpu(device)
         self.max_windows = int(max_windows)

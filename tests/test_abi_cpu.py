@@ -105,7 +105,10 @@ def test_c3d_kernel_names_and_flags_host_only():
     f32 = names(0, 1024, dtype=_lib.RGP_F32)
     assert f32[0] == 'igemm_kernel<128x64,f32,pool4>' and f32[3] == 'igemm_stagger_kernel<256x128,f32,pool8>'
     h = ctypes.c_void_p()
-    assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, 8) == -1                      # unknown flag
+    assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, 16) == -1                     # unknown flag
+    # RGP_C3D_CONV2A_ROWWISE: conv2a's inference forward on the row-wise fetch, nothing else changes
+    r = names(_lib.RGP_C3D_CONV2A_ROWWISE, 1024)
+    assert r[1] == 'conv_patch_bf16_kernel<64,128,56,16,pool8>' and r[0] == d[0] and r[2:] == d[2:]
     assert lib.rgp_c3d_create_ex(ctypes.byref(h), 2, _lib.RGP_BF16, _lib.RGP_C3D_KERNELS_TILE128) == -1
     assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, 8) == -1           # unknown flag
     assert lib.rgp_grcn_create(ctypes.byref(h), 2, 2, 512, 128, _lib.RGP_BF16, _lib.RGP_GRCN_PER_STEP) == 0

@@ -196,3 +196,28 @@ def test_odd_window_counts_are_window_independent(gpu, c3d_case, n):
     # a larger engine run with fewer windows than its capacity: rows beyond n stay untouched by the tail tiles
     f8b = big.forward(v8[:n].contiguous())[0]
     assert torch.equal(f8b[:n], f8[:n])
+
+
+def test_conv2a_slab_and_rowwise_fetch_are_bit_identical(gpu, c3d_case):
+    """conv2a + pool2 of inference plans runs on the plane-slab variant of the patch kernel (conv_patch_slab.hip.h); a plan
+    created with RGP_C3D_CONV2A_ROWWISE runs the row-wise fetch of conv_patch.hip.h (what training plans use).  Same
+    operands, same K order, same accumulation order inside a lane: the pooled conv2a output and everything downstream
+    must be EQUAL, bit for bit -- at 3 windows (ragged tile walk) and at 96 (persistent walk over several rounds)."""
+    from recurrent_gaze_prediction_amd.engine import C3DEngine
+    p = c3d_case[0]
+    for n in (3, 96):
+        g = torch.Generator(device=gpu)
+        g.manual_seed(700 + n)
+        video = torch.rand(n, 16, 112, 112, 3, device=gpu, generator=g) - 0.5
+        a = C3DEngine(n, dtype='bf16', device=gpu)
+        b = C3DEngine(n, dtype='bf16', device=gpu, kernels='patch-rowwise')
+        a.set_weights(p)
+        b.set_weights(p)
+        assert a.layer_kernel_name(1, n).startswith('conv_patch_slab_bf16_kernel<64,128,56,16')
+        assert b.layer_kernel_name(1, n).startswith('conv_patch_bf16_kernel<64,128,56,16')
+        ra = a.forward(video, want_features=False, want_rows=True)[1]
+        rb = b.forward(video, want_features=False, want_rows=True)[1]
+        la, lb = a.read_layer(1, n), b.read_layer(1, n)
+        assert float(la.abs().max()) > 0
+        assert torch.equal(la, lb), 'pooled conv2a output differs between the two fetch variants'
+        assert torch.equal(ra, rb)
