@@ -307,6 +307,7 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
   // fragment read r of step S (0-7: dY output tile r / 2, half r & 1; 8-21: X unit (r - 8) / 2, half r & 1)
   auto read1 = [&](auto S, int r, WgpFrags& f) {
     constexpr int s = decltype(S)::value;
+    if (r >= 20 && bias_unit) return;                         // the bias wave's seventh fragment stays all ones (below)
     if constexpr (P14) {                                      // step s = x pair s; half h = planes + 2 h
       const int h = r & 1;
       if (r < 8) {
@@ -344,14 +345,6 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(f.bl[j]), "+v"(f.bh[j]));
 #pragma unroll
     for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(f.al[i]), "+v"(f.ah[i]));
-    // the bias unit's A fragment is all ones (bf16): acc[6][j] = column sums of dY.  Written HERE, 24 MFMAs ahead of its
-    // use: the MFMAs are inline asm, so the compiler pads no VALU-write -> MFMA-read hazard for them (a select placed
-    // directly in front of the unit's first MFMA made that MFMA read the old registers)
-    if (bias_unit) {
-      f.al[6] = (i32x2_wg){0x3F803F80, 0x3F803F80};
-      f.ah[6] = (i32x2_wg){0x3F803F80, 0x3F803F80};
-    }
-    asm volatile("" : "+v"(f.al[6]), "+v"(f.ah[6]));
   };
   // the 28 MFMAs of a step on `cur`, with the 22 fragment reads of step S (of this group, or step 0 of the next one)
   // into `nxt` issued one behind each of the first 22: the wave never stops feeding the matrix pipe to issue reads
@@ -373,6 +366,8 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
   };
   // steps 0 .. 5 of a group whose step-0 fragments are in flight in fa; leaves step 6's in flight in fa
   auto steps_0_5 = [&](WgpFrags& fa, WgpFrags& fb) {
+    // (measured and not kept, round 5: entering a step on counted lgkmcnt waits per unit -- 12, 14, 15 -- instead of one
+    // full wait: fine-tune step 41.4 - 41.7 vs 41.4 - 41.5 ms, no gain: the SIMD's other wave covers the wait)
     landed(fa); step(std::integral_constant<int, 1>{}, fa, fb);
     landed(fb); step(std::integral_constant<int, 2>{}, fb, fa);
     landed(fa); step(std::integral_constant<int, 3>{}, fa, fb);
@@ -407,6 +402,12 @@ static __global__ __launch_bounds__(512) void wgrad_patch_bf16_kernel(const Wgra
   };
 
   WgpFrags f0, f1;
+  // the bias unit's A fragment is all ones (bf16): acc[6][j] = column sums of dY.  Written ONCE, here -- that wave issues no
+  // reads into these registers (read1) -- and never next to its use: the MFMAs are inline asm, so the compiler pads no
+  // VALU-write -> MFMA-read hazard for them (a select placed directly in front of the unit's first MFMA made that MFMA read
+  // the old registers)
+  f0.al[6] = f0.ah[6] = f1.al[6] = f1.ah[6] = (i32x2_wg){0x3F803F80, 0x3F803F80};
+  asm volatile("" : "+v"(f0.al[6]), "+v"(f0.ah[6]), "+v"(f1.al[6]), "+v"(f1.ah[6]));
   if constexpr (P14) {
     // the halo planes of the row slots are never fetched: zero the ring once (LDS writes, drained before the first DMA)
     for (int o = tid * 16; o < C::DY_OFF; o += 512 * 16) *(u32x4*)(wp_smem + o) = (u32x4){0u, 0u, 0u, 0u};
