@@ -338,7 +338,9 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       // only built on demand by rgp_c3d_read_grad_image
       const bool rows8 = sizeof(T) == 2 && ll.pd == 2 && ll.ph == 2 && (ll.cout == 128 || ll.cout == 256 || ll.cout == 512) &&
                          (ll.cout != 128 || (ll.H / 2) % 2 == 0) && dev_knob("RGP_UNPOOL_ROWS", 1);
-      if (rows8) {
+      if (rows8 && dev_knob("RGP_UNPOOL_SKIP", 0)) {
+        // dev pricing (timing only): no un-pool launch -- the consumers read the gradient image an earlier step left
+      } else if (rows8) {
         const int Hp = ll.H + 2;
         const int q_dz = Hp * Hp * ll.cout, q_dy = Hp * ll.cout;
         const bf16_t* dyp = (const bf16_t*)(ws + c->dyp_off);

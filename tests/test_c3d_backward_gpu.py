@@ -213,7 +213,7 @@ def test_backward_composition_under_the_devices_own_decisions(gpu, case):
     gradient (torch's arg-max of the recomputed conv output where the device's window is all zero) -- and otherwise runs on
     its own: the gradient it propagates from layer to layer is its own fp32 one (never re-seeded from the device, unlike the
     operator-local test), with torch.nn.grad operators.  What is left is the rounding of bf16 operands and of the bf16
-    gradient images through eight layers: every filter and bias gradient within 2e-2 (relative Frobenius error)."""
+    gradient images through eight layers: every filter and bias gradient within 1e-2 (relative Frobenius error)."""
     from recurrent_gaze_prediction_amd.engine import C3DEngine
     p, video, g = case
     n = video.shape[0]
@@ -264,7 +264,7 @@ def test_backward_composition_under_the_devices_own_decisions(gpu, case):
     finally:
         torch.set_num_threads(old)
     print('composition under device decisions, relative Frobenius error per gradient:', {k: '%.2e' % v for k, v in errs.items()})
-    assert max(errs.values()) < 2e-2, errs
+    assert max(errs.values()) < 1e-2, errs          # measured: 1.7e-3 (conv5b) ... 4.7e-3 (conv1a), growing with depth
 
 
 def torch_ref_out_shape(i):
