@@ -40,7 +40,7 @@ HEAD_FLOPS = {'proj': 51.38e6, 'xconv': 173.41e6, 'convgru_seq': 43.35e6, 'head'
 HEAD_FLOPS_FRAME = 432.79e6
 C3D_FLOPS_FRAME = sum(C3D_FLOPS.values())          # 76 993.27 MFLOP
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
-PMC_SUMMARY = 'profiles/r04_pmc_summary.json'      # separate rocprofv3 --pmc passes of the default command (scripts/r04_profiles.sh)
+PMC_SUMMARY = 'profiles/r05_pmc_summary.json'      # separate rocprofv3 --pmc passes of the default command (scripts/r05_profiles.sh)
 
 
 def parse():

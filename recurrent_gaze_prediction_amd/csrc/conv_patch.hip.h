@@ -65,7 +65,7 @@
 #define RGP_CP_CHUNK28 16    // ... 28 x 28 planes (8: conv3b 2 x FETCH 12.8 GB, 16 and 32: 11.1 GB; times equal)
 #endif
 #ifndef RGP_PLANE_AUX
-#define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured)
+#define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured, see docs/HISTORY.md)
 #endif
 
 namespace rgp {
@@ -198,7 +198,7 @@ static __global__ __launch_bounds__(512) void conv_patch_bf16_kernel(const ConvP
 #ifdef RGP_DEV_KNOBS
   // dev experiment (RGP_CP_ABLATE bits 8..15 = n): block i of an XCD starts i * n * 0.43 us late, so that the 32 CUs of an
   // XCD read the filter out of phase (every slab is then re-touched 32 times per tile time instead of once: it stays in
-  // L2).  Measured: traffic beyond L2 falls, time RISES -- the re-streams are not what these kernels wait for.
+  // L2).  Measured (docs/HISTORY.md): traffic beyond L2 falls, time RISES -- the re-streams are not what these kernels wait for.
   if ((p.ablate >> 8) & 0xff) {
     const int n = ((p.ablate >> 8) & 0xff) * (blockIdx.x >> 3);
     for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(16);

@@ -33,7 +33,7 @@
 #define RGP_MMA_ORDER 1     // 1: filter fragment outermost in a step (7 consecutive MFMAs share it; 0: the activation fragment, 4): -0.5 % wall
 #endif
 #ifndef RGP_PLANE_AUX
-#define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured)
+#define RGP_PLANE_AUX 0      // cache policy of the plane-slab LDS-DMA (2 = nt; measured, see docs/HISTORY.md)
 #endif
 
 namespace rgp {

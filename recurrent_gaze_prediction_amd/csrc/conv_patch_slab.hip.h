@@ -86,7 +86,7 @@ static __global__ __launch_bounds__(512) void conv_patch_slab_bf16_kernel(const 
 #ifdef RGP_DEV_KNOBS
   // dev experiment (RGP_CP_ABLATE bits 8..15 = n): block i of an XCD starts i * n * 0.43 us late, so that the 32 CUs of an
   // XCD read the filter out of phase (every slab is then re-touched 32 times per tile time instead of once: it stays in
-  // L2).  Measured: traffic beyond L2 falls, time RISES -- the re-streams are not what these kernels wait for.
+  // L2).  Measured (docs/HISTORY.md): traffic beyond L2 falls, time RISES -- the re-streams are not what these kernels wait for.
   if ((p.ablate >> 8) & 0xff) {
     const int n = ((p.ablate >> 8) & 0xff) * (blockIdx.x >> 3);
     for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(16);

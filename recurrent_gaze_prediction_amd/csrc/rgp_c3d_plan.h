@@ -33,7 +33,7 @@ struct rgp_c3d {
   bool use_patch() const { return dtype == RGP_BF16 && !(kernels & RGP_C3D_KERNELS_IGEMM); }
   bool tile128() const { return (kernels & RGP_C3D_KERNELS_TILE128) != 0; }
   // conv2a's INFERENCE forward on the plane-slab variant of the patch kernel (conv_patch_slab.hip.h) instead of the row-wise
-  // one (conv_patch.hip.h): same operands, bit-identical results; chosen by a same-box A/B and
+  // one (conv_patch.hip.h): same operands, bit-identical results; chosen by a same-box A/B (profiles/r05_ab_conv2a_slab.txt) and
   // switched off per plan by RGP_C3D_CONV2A_ROWWISE.  Training plans (arg-max codes recorded) stay on the row-wise kernel:
   // the slab variant's training forward measured 4 % slower.
   bool conv2a_slab() const { return use_patch() && !save && !(kernels & RGP_C3D_CONV2A_ROWWISE) && rgp::dev_knob("RGP_C2A_SLAB", 1) != 0; }

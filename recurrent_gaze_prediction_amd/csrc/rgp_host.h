@@ -39,7 +39,7 @@ int set_err(int code, const char* fmt, ...);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Development switches (ablations, tile-order experiments: DESIGN.md section 4) exist only in a build made with
+// Development switches (ablations, tile-order experiments: docs/HISTORY.md, "Development switches") exist only in a build made with
 // `make DEV=1`; the product library reads no environment variable and keeps no per-process tuning state.
 #ifdef RGP_DEV_KNOBS
 inline int dev_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }

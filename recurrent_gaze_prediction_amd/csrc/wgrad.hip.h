@@ -17,7 +17,7 @@
 // Block tile: 4 K-chunks (4 x 64 bf16 / 4 x 32 fp32 filter rows) x BN = 32*WNT output channels, 8 waves as
 // 4 (chunk) x 2 (16*WNT columns); the reduction is split over blockIdx.y and combined with fp32 atomics.
 // WNT = 4 (BN 128, two blocks per CU) or 8 (BN 256, one block per CU: a third fewer LDS-DMA bytes and a quarter
-// fewer fragment reads per FLOP -- the kernel is LDS-DMA-ingest bound).
+// fewer fragment reads per FLOP -- the kernel is LDS-DMA-ingest bound, docs/HISTORY.md section 4).
 // 3-stage DMA ring, one raw barrier per 32-row step, counted vmcnt.
 #pragma once
 #include "igemm.hip.h"
