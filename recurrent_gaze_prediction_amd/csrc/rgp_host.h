@@ -223,7 +223,17 @@ struct PackBatch {
     q.ntaps = d.pack_taps; q.cin_k = d.cin_k; q.cin_src = d.cin_src; q.n_rows = n_rows; q.row0 = row0; q.K = d.K; q.k0 = k0;
     q.grouped = grouped; q.row_step = row_step; q.chunk_major = d.chunk_major;
     int nb;
-    if (!grouped && d.s_n == 1 && d.cin_k >= 32 && n_rows >= 32) {      // as pack_filter(): tiled transpose
+    // whole 64-channel chunks of a bf16 pack with 16-byte aligned rows on both sides: the vector forms (kernels_misc.hip.h)
+    const bool wide = sizeof(T) == 2 && !grouped && row_step == 1 && d.cin_k % 64 == 0 && d.cin_src == d.cin_k && d.K % 8 == 0 &&
+                      k0 % 8 == 0 && (d.chunk_major == 0 || d.chunk_major % 64 == 0) && ((size_t)src & 15) == 0 && d.s_tap % 4 == 0 &&
+                      (d.w_off & 15) == 0;
+    if (wide && d.s_n == 1 && d.s_c % 4 == 0 && n_rows % 64 == 0) {
+      q.tiled = 2; q.gx = d.cin_k / 64; q.gy = n_rows / 64;
+      nb = q.gx * q.gy * d.pack_taps;
+    } else if (wide && d.s_c == 1 && d.s_n % 4 == 0) {
+      const long long groups = (long long)n_rows * d.pack_taps * (d.cin_k / 8);
+      q.tiled = 3; q.gy = 1; q.gx = nb = (int)std::min<long long>((groups + 255) / 256, 4096);
+    } else if (!grouped && d.s_n == 1 && d.cin_k >= 32 && n_rows >= 32) {      // as pack_filter(): tiled transpose
       q.tiled = 1; q.gx = (d.cin_k + 31) / 32; q.gy = (n_rows + 31) / 32;
       nb = q.gx * q.gy * d.pack_taps;
     } else {
