@@ -119,8 +119,20 @@ from recurrent_gaze_prediction_amd.models import gaze_rnn
 seed = (0 * 1000003 + 7919 * rank + 12345) & 0x7fffffff
 # a failure on ONE rank is seen by all of them (dp_train_probe exits every rank together)
 agree = [rdist.all_ranks_ok(d, True), rdist.all_ranks_ok(d, rank != world - 1 or world == 1)]
+# a persistent-launch time-out on ONE rank is counted on all of them (dp_train_probe: every rank then rebuilds its engine on
+# per-step launches together); per_rank clocks come back in rank order
+from recurrent_gaze_prediction_amd import _lib
+class TimedOut(object):
+    def __init__(self, fail): self.fail = fail
+    def status(self):
+        if self.fail:
+            e = _lib.RgpError('lost member'); e.code = _lib.RGP_ETIMEOUT
+            raise e
+lost = [rdist.engine_timeouts_all_ranks(d, TimedOut(world > 1 and rank == world - 1), 'cpu'),
+        rdist.engine_timeouts_all_ranks(d, TimedOut(False), 'cpu')]
+clocks = rdist.gather_over_ranks(d, 10.0 + rank)
 print(json.dumps({'rank': rank, 'world': world, 'W': eng.flat_params.tolist(), 'norms': norms, 'flip_seed': seed,
-                  'bytes': red.bytes_reduced, 'buckets': red.buckets_reduced, 'agree': agree}), flush=True)
+                  'bytes': red.bytes_reduced, 'buckets': red.buckets_reduced, 'agree': agree, 'lost': lost, 'clocks': clocks}), flush=True)
 if d is not None:
     d.barrier(); d.destroy_process_group()
 ''' % ROOT
@@ -151,7 +163,8 @@ def test_two_rank_dp_step_reproduces_the_full_batch_step(tmp_path):
         assert np.allclose(r['norms'], one['norms'], rtol=1e-12)      # the clip saw the global-batch gradient
         assert r['bytes'] == 3 * 24 * 8 and r['buckets'] == 6         # both buckets, every step, reduced in place
         assert r['agree'] == [True, False]                            # the last rank's failure reaches rank 0 too
-    assert one['agree'] == [True, True]
+        assert r['lost'] == [1, 0] and r['clocks'] == [10.0, 11.0]   # rank 1's time-out is seen by rank 0; clocks in rank order
+    assert one['agree'] == [True, True] and one['lost'] == [0, 0] and one['clocks'] == [10.0]
     assert one['norms'][0] > 0.05                                     # the clip was active
     assert two[0]['flip_seed'] != two[1]['flip_seed']
 
