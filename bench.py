@@ -256,8 +256,11 @@ def main():
                 from recurrent_gaze_prediction_amd import _lib as rlib
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)) as fh:
                     pmc = json.load(fh)
-                stem = ','.join(kname.replace(' ', '').split(',')[:4])      # kernel<CIN,NOUT,HW,D
-                hit = [v for k, v in pmc.items() if ','.join(k.replace(' ', '').split(',')[:4]) == stem and 'hbm_bytes_per_launch' in v]
+                def stem_of(name):                                          # kernel<CIN,NOUT,HW,D (whatever follows the fourth number)
+                    head, _, rest = name.replace(' ', '').partition('<')
+                    return head + '<' + ','.join(rest.replace('>', ',').split(',')[:4])
+                stem = stem_of(kname)
+                hit = [v for k, v in pmc.items() if stem_of(k) == stem and 'hbm_bytes_per_launch' in v]
                 # the counters belong to the build they were taken with: compare the sources of this kernel
                 then = pmc.get('_meta', {}).get('kernel_source_hashes', {})
                 now = rlib.kernel_source_hashes()

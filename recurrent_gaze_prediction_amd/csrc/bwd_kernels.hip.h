@@ -310,6 +310,22 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
   }
 }
 
+// The recurrent filter gradients' two operand images in one pass: h_{t-1} and r . h_{t-1} of every step, fp32 [rows][C]
+// -> halo-padded T images (round 4: a multiply into a scratch array and two pad_rows launches)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_h_rh_kernel(const float* __restrict__ r, const float* __restrict__ h, T* __restrict__ hp,
+                                                       T* __restrict__ rhp, const int* __restrict__ pad_tab, long long total, int C) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int p = (int)((i / C) % 49);
+    const long long f = i / ((long long)C * 49);
+    const long long o = f * 81 * C + pad_tab[p] + c;
+    const float hv = h[i];
+    hp[o] = Elem<T>::to(hv);
+    rhp[o] = Elem<T>::to(r[i] * hv);
+  }
+}
+
 // ---- optimizer (base.py:262-308; TF semantics) ------------------------------
 // partial[b] = sum of squares of block b's grid-stride share (deterministic two-stage norm)
 // (16-byte loads, four in flight per thread: the scalar loop it replaces read 123 MB -- the 30.7 M gradients of the
@@ -345,18 +361,37 @@ static __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict
                                                         float lr_t, float b1, float b2, float eps,
                                                         float* __restrict__ norm_out, const float* __restrict__ lr_t_dev) {
   if (lr_t_dev) lr_t = *lr_t_dev;       // step size computed on the device (graph-replayable training step)
+  // global norm from the partial sums: every lane adds its share, then a butterfly over the wave -- each stage adds the two
+  // partners' values (a + b == b + a exactly), so every lane of every wave ends with the SAME bits, hence the same scale.
+  // (Round 4 had every thread add all partials one after the other: 256 - 512 dependent adds in front of a 43 us kernel.)
   float sq = 0.f;
-  for (int i = 0; i < n_partial; ++i) sq += sq_partial[i];     // same order in every thread
+  for (int i = threadIdx.x & 63; i < n_partial; i += 64) sq += sq_partial[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
   const float norm = sqrtf(sq);
   const float scale = clip > 0.f ? clip / fmaxf(norm, clip) : 1.f;
   if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float gi = g[i] * scale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+  auto upd = [&](float gi, float& mi, float& vi, float& pi) {
+    gi *= scale;
+    mi = b1 * mi + c1 * gi;
+    vi = b2 * vi + c2 * gi * gi;
+    pi -= lr_t * mi / (sqrtf(vi) + eps);
+  };
+  // whole 16-byte groups where the four arrays are 16-byte aligned (flat buffers are), then the tail
+  const bool al = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
+  const long long n4 = al ? n >> 2 : 0;
+  for (long long i = tid; i < n4; i += stride) {
+    f32x4 G = ((const f32x4*)g)[i], M = ((f32x4*)m)[i], V = ((f32x4*)v)[i], P = ((f32x4*)p)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float mi = M[e], vi = V[e], pi = P[e]; upd(G[e], mi, vi, pi); M[e] = mi; V[e] = vi; P[e] = pi; }
+    ((f32x4*)m)[i] = M; ((f32x4*)v)[i] = V; ((f32x4*)p)[i] = P;
+  }
+  for (long long i = 4 * n4 + tid; i < n; i += stride) {
+    float mi = m[i], vi = v[i], pi = p[i];
+    upd(g[i], mi, vi, pi);
+    m[i] = mi; v[i] = vi; p[i] = pi;
   }
 }
 

@@ -29,7 +29,7 @@ struct GrcnBwd {
   std::vector<int> t_y, t_pad3S, t_pad2S, koff_c;
   size_t o_y = 0, o_pad3S = 0, o_pad2S = 0, o_koff_c = 0;
   long long M = 0, M2 = 0, Mp = 0, M2p = 0;
-  Buf dz, frame_sum, dgp, gp, dd2, dd1, dy, dh_head, dh_carry, drh, dcp_pad, dzr_pad, dxpre, dxpre_pad, dE, rh_all;
+  Buf dz, frame_sum, dgp, gp, dd2, dd1, dy, dh_head, dh_carry, drh, dcp_pad, dzr_pad, dxpre, dxpre_pad, dE;
   Buf xch_c, xch_z, xch_r, bptt_cnt;       // persistent BPTT kernel (convgru_bptt.hip.h): exchange images + phase counters
   Buf hp_all, rhp_all, dzb, ptoep, sq_partial;   // dzb / ptoep: blocked dz and the Toeplitz partial sums of the head filter gradient     // halo-padded h_{t-1} and r.h_{t-1} of every step, [t][b][9][9][S] (wgrad operands)
   rgp_grcn_weights w;   // forward weights (device fp32) as last set
@@ -317,9 +317,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   {
     const long long tot = (long long)T_ * B * 49 * S;
     const int nb = (int)std::min<long long>((tot + 255) / 256, 8192);
-    mul_kernel<<<nb, 256, 0, s>>>(Fp(g->rall), Fp(g->hall), Fp(b->rh_all), tot);
-    pad_rows_kernel<T><<<nb, 256, 0, s>>>(Fp(g->hall), Tp(b->hp_all), I(b->o_y), tot, S);       // h_{t-1}, [t][b][9][9][S]
-    pad_rows_kernel<T><<<nb, 256, 0, s>>>(Fp(b->rh_all), Tp(b->rhp_all), I(b->o_y), tot, S);   // r . h_{t-1}
+    // h_{t-1} and r . h_{t-1} of every step, [t][b][9][9][S]
+    pad_h_rh_kernel<T><<<nb, 256, 0, s>>>(Fp(g->rall), Fp(g->hall), Tp(b->hp_all), Tp(b->rhp_all), I(b->o_y), tot, S);
     RGP_HIP(hipGetLastError());
     WgradParams p = wg_params();
     p.y_sx = 3 * S; p.y_sy = 27 * S; p.y_org = 30 * S;
@@ -497,7 +496,6 @@ int grcn_bwd_plan(rgp_grcn* g, Arena& a) {
   b->dxpre = take(a, (size_t)F * 49 * 3 * S * 4);
   b->dxpre_pad = take(a, (size_t)F * 81 * 3 * S * es);
   b->dE = take(a, (size_t)(b->M + 1) * P * es);        // + a leading zero row
-  b->rh_all = take(a, st * T_);
   if (g->seq_groups > 0) {
     b->xch_c = take(a, (size_t)g->seq_groups * 98 * 128 * 2);
     b->xch_z = take(a, (size_t)g->seq_groups * 98 * 128 * 2);

@@ -1,0 +1,7 @@
+# Dev (GPU box): head training steps (config 4: 8 clips x T = 35; config 3: 64 x 16) of the in-tree library against another
+# build, alternating processes.   bash scripts/dev_ab_train.sh <other lib.so> [rounds] [out file]
+OTHER=${1:-recurrent_gaze_prediction_amd/librgp_hip_prev.so}; R=${2:-3}; O=${3:-gpurun_out/r05/ab_train.txt}
+for r in $(seq $R); do for lib in recurrent_gaze_prediction_amd/librgp_hip.so $OTHER; do
+timeout -k 10 200 python scripts/dev_with_lib.py $lib bench.py --workload train --batch 8 --n-steps 35 --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib  train B8xT35 %.4f ms' % j['ms_per_step'])"
+timeout -k 10 200 python scripts/dev_with_lib.py $lib bench.py --workload train --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib  train B64xT16 %.4f ms' % j['ms_per_step'])"
+done; done | tee $O
