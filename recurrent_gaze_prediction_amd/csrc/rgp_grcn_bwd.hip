@@ -37,8 +37,18 @@ struct GrcnBwd {
   // output layer, 1 = the six ConvGRU filters, 2 = the projection (= end of the backward)
   hipEvent_t grad_ev[3] = {nullptr, nullptr, nullptr};
   bool grad_ev_made = false, grad_ev_recorded = false;
+  // The folded head's chain rule (dK -> dF1, dH, dF2, dG, dF3, d out_W: six small dependent kernels, 63 us at config 4's shape)
+  // feeds nothing the rest of the backward reads: it runs on a stream of the plan's own, beside the dy GEMM, the batch-norm
+  // backward and the BPTT launch (which leaves CUs free at <= 24 clips; at more it is simply queued behind them), and is
+  // joined at the end of the call.  Not while the caller's stream is being captured.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_bn = nullptr, ev_join = nullptr;
   ~GrcnBwd() {
     if (grad_ev_made) for (int i = 0; i < 3; ++i) (void)hipEventDestroy(grad_ev[i]);
+    if (side) {
+      (void)hipStreamDestroy(side);
+      (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_bn); (void)hipEventDestroy(ev_join);
+    }
   }
 };
 
@@ -109,6 +119,13 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // (not while `s` is being captured into a graph: a replay runs on one stream and has nobody to signal)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool mark = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone);
+  const bool fork = mark && g->fold_head && !ext_dy;             // the folded head's chain rule on the plan's side stream
+  if (fork && !b->side) {
+    RGP_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    RGP_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    RGP_HIP(hipEventCreateWithFlags(&b->ev_bn, hipEventDisableTiming));
+    RGP_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+  }
 
   // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
   // slices of one flat buffer (engine.py: flat_grads), else one per tensor
@@ -168,12 +185,18 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     }
     const float* hf = (const float*)(ws + g->hf_h.off);
     const float* gf = (const float*)(ws + g->gfold.off);
-    head_unfold_f1_kernel<<<(25 * 64 * S + 255) / 256, 256, 0, s>>>(Fp(b->dkf), hf, (float*)gr->up_weight1, S);
-    head_unfold_h_kernel<<<dim3(HF_HP * HF_HP, 25), 256, 0, s>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhp), S);
-    head_fold_sum_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(Fp(b->dhp), Fp(b->dhf), HF_HP * HF_HP * 64, 25);
-    head_unfold_f2_kernel<<<(25 * 32 * 64 + 255) / 256, 256, 0, s>>>(Fp(b->dhf), gf, (float*)gr->up_weight2);
-    head_unfold_g_kernel<<<49, 256, 0, s>>>(Fp(b->dhf), b->w.up_weight2, Fp(b->dgp));
-    head_unfold_grads_kernel<<<1, 256, 0, s>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
+    hipStream_t sc = s;                                          // the chain's stream
+    if (fork) {
+      RGP_HIP(hipEventRecord(b->ev_fork, s));                    // dK is complete, the gradient buffers are zeroed
+      RGP_HIP(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+      sc = b->side;
+    }
+    head_unfold_f1_kernel<<<(25 * 64 * S + 255) / 256, 256, 0, sc>>>(Fp(b->dkf), hf, (float*)gr->up_weight1, S);
+    head_unfold_h_kernel<<<dim3(HF_HP * HF_HP, 25), 256, 0, sc>>>(Fp(b->dkf), b->w.up_weight1, Fp(b->dhp), S);
+    head_fold_sum_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, sc>>>(Fp(b->dhp), Fp(b->dhf), HF_HP * HF_HP * 64, 25);
+    head_unfold_f2_kernel<<<(25 * 32 * 64 + 255) / 256, 256, 0, sc>>>(Fp(b->dhf), gf, (float*)gr->up_weight2);
+    head_unfold_g_kernel<<<49, 256, 0, sc>>>(Fp(b->dhf), b->w.up_weight2, Fp(b->dgp));
+    head_unfold_grads_kernel<<<1, 256, 0, sc>>>(Fp(b->dgp), b->w.up_weight3, b->w.out_W, (float*)gr->up_weight3, (float*)gr->out_W);
     RGP_HIP(hipGetLastError());
     {
       IgemmParams p = make_params(b->b_hf, Tp(b->pm), ws, F);
@@ -253,7 +276,16 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // free (config 4: 8 clips per GPU = 64 workgroups); a launch that needs more than n_cu - RGP_RCCL_CU_RESERVE CUs
   // releases the group only behind itself (include/rgp.h, rgp_grcn_wait_grads).
   const bool top_early = !persistent || grads_top_early(g);
-  if (mark && top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], s));
+  if (fork) {
+    // the TOP group is final once BOTH the chain (side stream) and the batch-norm backward (this stream) are: its event is
+    // recorded on the side stream behind an event of this one -- ahead of the BPTT launch in queue order, as before
+    RGP_HIP(hipEventRecord(b->ev_bn, s));
+    RGP_HIP(hipStreamWaitEvent(b->side, b->ev_bn, 0));
+    if (top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], b->side));
+    RGP_HIP(hipEventRecord(b->ev_join, b->side));
+  } else if (mark && top_early) {
+    RGP_HIP(hipEventRecord(b->grad_ev[0], s));
+  }
   if (persistent) {
     RGP_HIP(hipMemsetAsync(ws + b->bptt_cnt.off, 0, b->bptt_cnt.bytes, s));      // phase counters: zeroed EVERY call
     BpttParams q;
@@ -280,6 +312,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_HIP(hipGetLastError());
     RGP_TRY(guard.commit());
   }
+  if (fork) RGP_HIP(hipStreamWaitEvent(s, b->ev_join, 0));              // the chain has ended (it had the whole BPTT launch to do so)
   if (mark && !top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], s));     // full-chip launch: the TOP group leaves behind it
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
