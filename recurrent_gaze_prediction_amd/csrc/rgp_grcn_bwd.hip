@@ -40,7 +40,7 @@ struct GrcnBwd {
   // The folded head's chain rule (dK -> dF1, dH, dF2, dG, dF3, d out_W: six small dependent kernels, 63 us at config 4's shape)
   // feeds nothing the rest of the backward reads: it runs on a stream of the plan's own, beside the dy GEMM, the batch-norm
   // backward and the BPTT launch (which leaves CUs free at <= 24 clips; at more it is simply queued behind them), and is
-  // joined at the end of the call.  Not while the caller's stream is being captured.
+  // joined at the end of the call (also inside a stream capture: the graph then has two branches).
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_bn = nullptr, ev_join = nullptr;
   ~GrcnBwd() {
@@ -119,7 +119,9 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // (not while `s` is being captured into a graph: a replay runs on one stream and has nobody to signal)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool mark = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone);
-  const bool fork = mark && g->fold_head && !ext_dy;             // the folded head's chain rule on the plan's side stream
+  // the folded head's chain rule on the plan's side stream.  While `s` is being captured the same fork / join is recorded into
+  // the graph (two parallel branches) -- provided the side stream exists already: streams are not created during a capture
+  const bool fork = g->fold_head && !ext_dy && (mark || b->side != nullptr);
   if (fork && !b->side) {
     RGP_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
     RGP_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -281,7 +283,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     // recorded on the side stream behind an event of this one -- ahead of the BPTT launch in queue order, as before
     RGP_HIP(hipEventRecord(b->ev_bn, s));
     RGP_HIP(hipStreamWaitEvent(b->side, b->ev_bn, 0));
-    if (top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], b->side));
+    if (mark && top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], b->side));
     RGP_HIP(hipEventRecord(b->ev_join, b->side));
   } else if (mark && top_early) {
     RGP_HIP(hipEventRecord(b->grad_ev[0], s));
