@@ -41,13 +41,17 @@ struct GrcnBwd {
   // feeds nothing the rest of the backward reads: it runs on a stream of the plan's own, beside the dy GEMM, the batch-norm
   // backward and the BPTT launch (which leaves CUs free at <= 24 clips; at more it is simply queued behind them), and is
   // joined at the end of the call (also inside a stream capture: the graph then has two branches).
+  // Behind the BPTT launch the same stream takes the six ConvGRU filter gradients (two grouped wgrad launches, each one
+  // round of blocks) while the calling stream runs the input convolutions' dgrad and the projection's gradients: neither
+  // branch reads what the other writes (ev_wfork / ev_wjoin).
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_bn = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_bn = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr;
   ~GrcnBwd() {
     if (grad_ev_made) for (int i = 0; i < 3; ++i) (void)hipEventDestroy(grad_ev[i]);
     if (side) {
       (void)hipStreamDestroy(side);
       (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_bn); (void)hipEventDestroy(ev_join);
+      (void)hipEventDestroy(ev_wfork); (void)hipEventDestroy(ev_wjoin);
     }
   }
 };
@@ -121,12 +125,13 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const bool mark = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone);
   // the folded head's chain rule on the plan's side stream.  While `s` is being captured the same fork / join is recorded into
   // the graph (two parallel branches) -- provided the side stream exists already: streams are not created during a capture
-  const bool fork = g->fold_head && !ext_dy && (mark || b->side != nullptr);
-  if (fork && !b->side) {
+  const bool side_ok = (mark || b->side != nullptr) && dev_knob("RGP_BWD_FORK", 1);
+  const bool fork = g->fold_head && !ext_dy && side_ok;
+  const bool wfork = side_ok && dev_knob("RGP_BWD_FORK", 1) != 2;
+  if (side_ok && !b->side) {
     RGP_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-    RGP_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-    RGP_HIP(hipEventCreateWithFlags(&b->ev_bn, hipEventDisableTiming));
-    RGP_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    for (hipEvent_t* e : {&b->ev_fork, &b->ev_bn, &b->ev_join, &b->ev_wfork, &b->ev_wjoin})
+      RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
 
   // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
@@ -278,6 +283,15 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // free (config 4: 8 clips per GPU = 64 workgroups); a launch that needs more than n_cu - RGP_RCCL_CU_RESERVE CUs
   // releases the group only behind itself (include/rgp.h, rgp_grcn_wait_grads).
   const bool top_early = !persistent || grads_top_early(g);
+  // h_{t-1} and r . h_{t-1} of every step, halo-padded [t][b][9][9][S]: the recurrent filter gradients' X operand (step 8)
+  bool h_rh_padded = false;
+  auto pad_h_rh = [&](hipStream_t q) -> int {
+    const long long tot = (long long)T_ * B * 49 * S;
+    const int nb = (int)std::min<long long>((tot + 255) / 256, 8192);
+    pad_h_rh_kernel<T><<<nb, 256, 0, q>>>(Fp(g->rall), Fp(g->hall), Tp(b->hp_all), Tp(b->rhp_all), I(b->o_y), tot, S);
+    RGP_HIP(hipGetLastError());
+    return RGP_OK;
+  };
   if (fork) {
     // the TOP group is final once BOTH the chain (side stream) and the batch-norm backward (this stream) are: its event is
     // recorded on the side stream behind an event of this one -- ahead of the BPTT launch in queue order, as before
@@ -285,6 +299,10 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_HIP(hipStreamWaitEvent(b->side, b->ev_bn, 0));
     if (mark && top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], b->side));
     RGP_HIP(hipEventRecord(b->ev_join, b->side));
+    if (wfork) {                                                           // forward-only operands: in the BPTT launch's shadow
+      RGP_TRY(pad_h_rh(b->side));
+      h_rh_padded = true;
+    }
   } else if (mark && top_early) {
     RGP_HIP(hipEventRecord(b->grad_ev[0], s));
   }
@@ -336,25 +354,23 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
     }
   }
-  // 7. hoisted input convs: dgrad -> dE, then the projection's gradients
+  // 7. hoisted input convs: the padded gradient image both branches below read
   {
     const long long tot = (long long)F * 49 * 3 * S;
     pad_rows_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>(Fp(b->dxpre), Tp(b->dxpre_pad),
                                                                                       I(b->o_pad3S), tot, 3 * S);
     RGP_HIP(hipGetLastError());
-    IgemmParams p = make_params(b->b_x, Tp(b->dxpre_pad), ws, F);
-    EpiParams e = make_epi(b->b_x, Tp(b->dE) + P, ws);        // row 0 of the buffer stays zero (wgrad_kernel's dY contract)
-    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
   }
-  // 8. weight gradients of the recurrence and the projection, hoisted over all T steps: wgrad_kernel straight on the
-  //    halo-padded operand images (no im2col / transposed copies).  Gate g's gradient columns are [gS, (g+1)S) of the
-  //    padded dxpre image.
+  hipStream_t sw = s;                                                      // the stream of the ConvGRU filter gradients
+  if (wfork) {
+    RGP_HIP(hipEventRecord(b->ev_wfork, s));
+    RGP_HIP(hipStreamWaitEvent(b->side, b->ev_wfork, 0));
+    sw = b->side;
+  }
+  // 8. weight gradients of the recurrence, hoisted over all T steps: wgrad_kernel straight on the halo-padded operand
+  //    images (no im2col / transposed copies).  Gate g's gradient columns are [gS, (g+1)S) of the padded dxpre image.
   {
-    const long long tot = (long long)T_ * B * 49 * S;
-    const int nb = (int)std::min<long long>((tot + 255) / 256, 8192);
-    // h_{t-1} and r . h_{t-1} of every step, [t][b][9][9][S]
-    pad_h_rh_kernel<T><<<nb, 256, 0, s>>>(Fp(g->rall), Fp(g->hall), Tp(b->hp_all), Tp(b->rhp_all), I(b->o_y), tot, S);
-    RGP_HIP(hipGetLastError());
+    if (!h_rh_padded) RGP_TRY(pad_h_rh(sw));
     WgradParams p = wg_params();
     p.y_sx = 3 * S; p.y_sy = 27 * S; p.y_org = 30 * S;
     p.N = S; p.ldw = S; p.M = M;
@@ -366,7 +382,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     // the three gates are three problems of one geometry (dY columns q S, their own dW): one grouped launch
     p.dY = Tp(b->dxpre_pad); p.dW = dWx[0]; p.nz = 3;
     for (int q = 0; q < 3; ++q) { p.zy[q] = (long long)q * S * sizeof(T); p.zw[q] = dWx[q] - dWx[0]; }
-    RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    RGP_TRY((launch_wgrad<T, 1>(p, sw)));
     // recurrent filters: image = clip b, z = step t (h images are step-major, gradient frames clip-major)
     wgrad_grid(p, T_, 7, 7);
     p.x_sx = S; p.x_sy = 9 * S; p.x_sz = B * 81 * S; p.x_img_stride = 81LL * S;
@@ -378,10 +394,18 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       p.zx[q] = q < 2 ? 0 : (const char*)Tp(b->rhp_all) - (const char*)Tp(b->hp_all);
       p.zy[q] = (long long)q * S * sizeof(T); p.zw[q] = dWh[q] - dWh[0];
     }
-    RGP_TRY((launch_wgrad<T, 1>(p, s)));
-    if (mark) RGP_HIP(hipEventRecord(b->grad_ev[1], s));               // the six ConvGRU filters are final
+    RGP_TRY((launch_wgrad<T, 1>(p, sw)));
+    if (mark) RGP_HIP(hipEventRecord(b->grad_ev[1], sw));              // the six ConvGRU filters are final
+    if (wfork) RGP_HIP(hipEventRecord(b->ev_wjoin, sw));
   }
-  {  // projection: one row per (frame, position), X = the 1024-channel C3D rows, dY = dE behind its zero row
+  // 9. the input convolutions' dgrad -> dE, then the projection's gradients: one row per (frame, position), X = the
+  //    1024-channel C3D rows, dY = dE behind its zero row
+  {
+    IgemmParams p = make_params(b->b_x, Tp(b->dxpre_pad), ws, F);
+    EpiParams e = make_epi(b->b_x, Tp(b->dE) + P, ws);        // row 0 of the buffer stays zero (wgrad_kernel's dY contract)
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+  }
+  {
     WgradParams p = wg_params();
     p.X = Tp(g->xt); p.dY = Tp(b->dE); p.dW = (float*)gr->proj_c3d_W;
     wgrad_grid(p, 1, 1, (int)M);
@@ -391,6 +415,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     dense_colsum_kernel<T><<<(int)std::min<long long>((M + 63) / 64, 1024), 256, 0, s>>>(Tp(b->dE) + P, M, P, (float*)gr->proj_c3d_b);
     RGP_HIP(hipGetLastError());
   }
+  if (wfork) RGP_HIP(hipStreamWaitEvent(s, b->ev_wjoin, 0));
   if (mark) {
     RGP_HIP(hipEventRecord(b->grad_ev[2], s));
     b->grad_ev_recorded = true;
