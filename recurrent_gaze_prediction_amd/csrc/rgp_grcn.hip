@@ -255,7 +255,7 @@ int head_impl(rgp_grcn* g, float* logits, hipStream_t s) {
 }
 
 template <typename T>
-int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
+int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s, hipStream_t sc) {
   char* ws = g->ws;
   const int S = g->S, P = g->P;
   PackBatch<T> pk(ws, s);       // every pack of this call in one launch, behind the fold / Toeplitz kernels it reads from
@@ -269,8 +269,9 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_TRY(pk.add(g->gzr, w->gru_Uz, S, 0));
   RGP_TRY(pk.add(g->gzr, w->gru_Ur, S, S));
   RGP_TRY(pk.add(g->gc, w->gru_U, S, 0));
+  // sc: the stream of the head's fold and the pack that reads it (= s, or a training plan's side stream: rgp_grcn_set_weights)
   float* gf = (float*)(ws + g->gfold.off);
-  fold_head_filter_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>(w->up_weight3, w->out_W, gf, 49, 12, 32);
+  fold_head_filter_kernel<<<(49 * 32 + 255) / 256, 256, 0, g->fold_head ? sc : s>>>(w->up_weight3, w->out_W, gf, 49, 12, 32);
   RGP_HIP(hipGetLastError());
   if (!g->fold_head) {                                         // the three-stage head's operand filters
     for (size_t i = 0; i < g->d1_pack.size(); ++i) RGP_TRY(pk.add(g->d1_pack[i], w->up_weight1, 64, (int)(i % 3) * 64));   // column phase px = i % 3
@@ -285,12 +286,14 @@ int set_weights_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
     // the head as one 19x19 stride-6 transposed convolution (head_fold.hip.h): G (above) -> H = G o weight2 -> K = H o weight1
     float* hf = (float*)(ws + g->hf_h.off);
     float* kf = (float*)(ws + g->hf_k.off);
-    head_fold_h_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, s>>>(gf, w->up_weight2, hf);
+    head_fold_h_kernel<<<(HF_HP * HF_HP * 64 + 255) / 256, 256, 0, sc>>>(gf, w->up_weight2, hf);
     float* part = (float*)(ws + g->hf_part.off);
-    head_fold_k_kernel<<<dim3(HF_KP * HF_KP, 5), 128, 0, s>>>(hf, w->up_weight1, part, S);
-    head_fold_sum_kernel<<<(HF_KP * HF_KP * S + 255) / 256, 256, 0, s>>>(part, kf, HF_KP * HF_KP * S, 5);
+    head_fold_k_kernel<<<dim3(HF_KP * HF_KP, 5), 128, 0, sc>>>(hf, w->up_weight1, part, S);
+    head_fold_sum_kernel<<<(HF_KP * HF_KP * S + 255) / 256, 256, 0, sc>>>(part, kf, HF_KP * HF_KP * S, 5);
     RGP_HIP(hipGetLastError());
-    RGP_TRY(pk.add(g->hfold, kf, HF_KP * HF_KP, 0));          // GEMM filter [(r,t)][s]; rows 361 .. 383 stay zero
+    PackBatch<T> pk2(ws, sc);
+    RGP_TRY(pk2.add(g->hfold, kf, HF_KP * HF_KP, 0));         // GEMM filter [(r,t)][s]; rows 361 .. 383 stay zero
+    RGP_TRY(pk2.flush());
   }
   RGP_TRY(pk.flush());
   g->bn_gamma = w->bn_gamma;
@@ -536,8 +539,11 @@ int rgp_grcn_set_weights(rgp_grcn_t* g, const rgp_grcn_weights* w, rgp_stream_t 
   for (size_t i = 0; i < sizeof(rgp_grcn_weights) / sizeof(float*); ++i)
     RGP_REQUIRE(ptrs[i], "rgp_grcn_set_weights: weight pointer %zu is null", i);
   hipStream_t s = (hipStream_t)stream;
-  RGP_TRY(g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s) : set_weights_impl<float>(g, w, s));
-  if (g->save) RGP_TRY(grcn_bwd_pack(g, w, s));
+  hipStream_t sc = s;
+  if (g->save) RGP_TRY(grcn_bwd_fork_fold(g, s, &sc));
+  RGP_TRY(g->dtype == RGP_BF16 ? set_weights_impl<bf16_t>(g, w, s, sc) : set_weights_impl<float>(g, w, s, sc));
+  if (g->save) RGP_TRY(grcn_bwd_pack(g, w, s, sc));
+  if (sc != s) RGP_TRY(grcn_bwd_join_fold(g, s));
   return RGP_OK;
 }
 

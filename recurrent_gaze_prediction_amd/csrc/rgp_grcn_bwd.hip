@@ -60,6 +60,14 @@ namespace {
 
 constexpr int SQ_BLOCKS = 256;
 
+int make_side_stream(GrcnBwd* b) {
+  if (b->side) return RGP_OK;
+  RGP_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&b->ev_fork, &b->ev_bn, &b->ev_join, &b->ev_wfork, &b->ev_wjoin})
+    RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  return RGP_OK;
+}
+
 size_t put(Arena& a, const std::vector<int>& t) { return a.take(t.size() * 4); }
 
 // Folded 7x7 head filter gradient dGp[u,v,c] = sum_{f,y,x} dz[f,y,x] d2pad[f,y+u,x+v,c] as seven wgrad_kernel launches
@@ -128,11 +136,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const bool side_ok = (mark || b->side != nullptr) && dev_knob("RGP_BWD_FORK", 1);
   const bool fork = g->fold_head && !ext_dy && side_ok;
   const bool wfork = side_ok && dev_knob("RGP_BWD_FORK", 1) != 2;
-  if (side_ok && !b->side) {
-    RGP_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&b->ev_fork, &b->ev_bn, &b->ev_join, &b->ev_wfork, &b->ev_wjoin})
-      RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  }
+  if (side_ok) RGP_TRY(make_side_stream(b));
 
   // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
   // slices of one flat buffer (engine.py: flat_grads), else one per tensor
@@ -428,7 +432,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
 }
 
 template <typename T>
-int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
+int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s, hipStream_t sc) {
   GrcnBwd* b = g->bwd;
   char* ws = g->ws;
   const int S = g->S, P = g->P;
@@ -446,8 +450,12 @@ int pack_impl(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
   RGP_TRY(pk.add(b->b_x, w->gru_Wz, P, 0, 0, 1));
   RGP_TRY(pk.add(b->b_x, w->gru_Wr, P, 0, S, 1));
   RGP_TRY(pk.add(b->b_x, w->gru_W, P, 0, 2 * S, 1));
-  if (g->fold_head) RGP_TRY(pk.add(b->b_hf, (const float*)(ws + g->hf_k.off), S, 0));     // K of the folded head (set_weights_impl built it)
   RGP_TRY(pk.flush());
+  if (g->fold_head) {                                          // K of the folded head: set_weights_impl built it on stream sc
+    PackBatch<T> pk2(ws, sc);
+    RGP_TRY(pk2.add(b->b_hf, (const float*)(ws + g->hf_k.off), S, 0));
+    RGP_TRY(pk2.flush());
+  }
   // Gp[u,v,c] = G[6-u,6-v,c] in fp32 for the folded-filter dgrad (G itself is in g->gfold)
   // (49*32 elements; reuse the pack kernel with T=float semantics is overkill: tiny copy kernel)
   return RGP_OK;
@@ -584,11 +592,34 @@ int grcn_bwd_upload(rgp_grcn* g, hipStream_t s) {
   return RGP_OK;
 }
 
-int grcn_bwd_pack(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s) {
+int grcn_bwd_pack(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s, hipStream_t sc) {
   g->bwd->w = *w;
-  RGP_TRY(g->dtype == RGP_BF16 ? pack_impl<bf16_t>(g, w, s) : pack_impl<float>(g, w, s));
-  flip_fold_kernel<<<(49 * 32 + 255) / 256, 256, 0, s>>>((const float*)(g->ws + g->gfold.off), (float*)(g->ws + g->bwd->gp.off));
+  RGP_TRY(g->dtype == RGP_BF16 ? pack_impl<bf16_t>(g, w, s, sc) : pack_impl<float>(g, w, s, sc));
+  flip_fold_kernel<<<(49 * 32 + 255) / 256, 256, 0, sc>>>((const float*)(g->ws + g->gfold.off), (float*)(g->ws + g->bwd->gp.off));
   RGP_HIP(hipGetLastError());
+  return RGP_OK;
+}
+
+// rgp_grcn_set_weights of a training plan: the head's fold (G -> H -> K: four dependent kernels) and the packs that read it run
+// on the plan's side stream beside the packs of the other filters.  *sc = the side stream, forked behind everything queued on s
+// (the optimizer step that wrote the weights); s itself when s is being captured and the side stream does not exist yet.
+int grcn_bwd_fork_fold(rgp_grcn* g, hipStream_t s, hipStream_t* sc) {
+  GrcnBwd* b = g->bwd;
+  *sc = s;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
+  if (!g->fold_head || (capturing && !b->side) || !dev_knob("RGP_BWD_FORK", 1)) return RGP_OK;
+  RGP_TRY(make_side_stream(b));
+  RGP_HIP(hipEventRecord(b->ev_fork, s));
+  RGP_HIP(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+  *sc = b->side;
+  return RGP_OK;
+}
+
+int grcn_bwd_join_fold(rgp_grcn* g, hipStream_t s) {
+  GrcnBwd* b = g->bwd;
+  RGP_HIP(hipEventRecord(b->ev_join, b->side));
+  RGP_HIP(hipStreamWaitEvent(s, b->ev_join, 0));
   return RGP_OK;
 }
 

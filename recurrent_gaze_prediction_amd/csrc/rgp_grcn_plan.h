@@ -52,5 +52,7 @@ bool grads_top_early(const rgp_grcn* g);
 int grcn_check_error(rgp_grcn* g);
 int grcn_bwd_plan(rgp_grcn* g, rgp::Arena& a);
 int grcn_bwd_upload(rgp_grcn* g, hipStream_t s);
-int grcn_bwd_pack(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s);
+int grcn_bwd_pack(rgp_grcn* g, const rgp_grcn_weights* w, hipStream_t s, hipStream_t sc);   // sc: the stream the head's fold ran on
+int grcn_bwd_fork_fold(rgp_grcn* g, hipStream_t s, hipStream_t* sc);
+int grcn_bwd_join_fold(rgp_grcn* g, hipStream_t s);
 void grcn_bwd_destroy(rgp_grcn* g);

@@ -175,6 +175,85 @@ static void run_pipe(const char* name, const bf16x8* src, float* out, unsigned l
     fflush(stdout);
 }
 
+
+// ---- v_mfma_f32_32x32x16_bf16: the same 4-register operands, twice the FLOPs per instruction (16 passes), i.e. half the
+// operand-register reads and instruction issues per FLOP.  ROW = 0: registers only; 1: row-wise LDS reads as row_kernel
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int NA, int NB, int THREADS, int ROW>
+__global__ __launch_bounds__(THREADS) void k32_kernel(const bf16x8* __restrict__ src, float* __restrict__ out, int iters,
+                                                      unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    bf16x8* lds = reinterpret_cast<bf16x8*>(smem);
+    for (int i = tid; i < 4096; i += THREADS) lds[i] = src[(blockIdx.x & 15) * 4096 + i];
+    __syncthreads();
+    bf16x8 a[NA], b[2][NB];
+    const bf16x8* p0 = lds + lane;
+    for (int i = 0; i < NA; ++i) a[i] = p0[64 * i];
+    for (int i = 0; i < NB; ++i) b[0][i] = b[1][i] = p0[64 * (i + NA)];
+    f32x16 acc[NA * NB];
+    for (int i = 0; i < NA * NB; ++i) for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int BPR = (NB + NA - 1) / NA;
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bf16x8* p = p0 + (h ? 0 : 2048 - 64 * (NA + NB));
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i * NB + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[h][j], acc[i * NB + j], 0, 0, 0);
+                if (ROW) {
+                    a[i] = p[64 * i];
+#pragma unroll
+                    for (int q = 0; q < BPR; ++q)
+                        if (i * BPR + q < NB) b[h ^ 1][i * BPR + q] = p[64 * (NA + i * BPR + q)];
+                } else {
+                    asm volatile("" : "+v"(a[i]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < NA * NB; ++i) for (int q = 0; q < 16; ++q) s += acc[i][q];
+    out[blockIdx.x * THREADS + tid] = s;
+    if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int NA, int NB, int THREADS, int ROW>
+static void run32(const char* name, const bf16x8* src, float* out, unsigned long long* stamps, int nblk) {
+    const int iters = 20000 * 14 / (NA * NB);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto k = &k32_kernel<NA, NB, THREADS, ROW>;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    float ms = 0;
+    do {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 10; ++i) k<<<nblk, THREADS, 65536>>>(src, out, iters, stamps);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float m; CHECK(hipEventElapsedTime(&m, e0, e1)); ms += m;
+    } while (ms < 2500.f);
+    const int reps = 20;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) k<<<nblk, THREADS, 65536>>>(src, out, iters, stamps);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> st(2 * nblk);
+    CHECK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> clk(nblk);
+    for (int i = 0; i < nblk; ++i) clk[i] = double(st[2 * i]) / double(st[2 * i + 1]) * 0.1;
+    std::sort(clk.begin(), clk.end());
+    double flop = double(reps) * nblk * (THREADS / 64) * double(iters) * NA * NB * 32 * 32 * 16 * 2;
+    double cyc = double(st[0]) / (double(iters) * NA * NB);
+    printf("%-44s %8.1f TFLOP/s  in-kernel clock %.3f GHz  %.2f cycles per MFMA and wave  %.2f ms/launch\n", name,
+           flop / (ms * 1e-3) * 1e-12, clk[nblk / 2], cyc, ms / reps);
+    fflush(stdout);
+}
+
 template <int MODE>
 static void run(const char* name, const bf16x8* src, float* out, unsigned long long* stamps, int nblk) {
     const int iters = 20000;
@@ -206,8 +285,9 @@ static void run(const char* name, const bf16x8* src, float* out, unsigned long l
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int nblk = 256;
+    const bool only32 = argc > 1;
     std::vector<unsigned short> h(16 * 4096 * 8);
     srand(1);
     for (auto& v : h) {
@@ -219,6 +299,16 @@ int main() {
     CHECK(hipMalloc(&src, h.size() * 2)); CHECK(hipMalloc(&out, nblk * 512 * 4)); CHECK(hipMalloc(&stamps, nblk * 16));
     CHECK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     run<0>("registers only, 2 waves/SIMD", src, out, stamps, nblk);
+    run32<4, 2, 512, 0>("32x32x16 registers only, 4x2, 2 waves/SIMD", src, out, stamps, nblk);
+    run32<3, 2, 512, 0>("32x32x16 registers only, 3x2, 2 waves/SIMD", src, out, stamps, nblk);
+    run32<4, 2, 512, 1>("32x32x16 row-wise 4x2 (6 per 8), 2 waves/SIMD", src, out, stamps, nblk);
+    run32<3, 2, 512, 1>("32x32x16 row-wise 3x2 (5 per 6), 2 waves/SIMD", src, out, stamps, nblk);
+    run32<2, 2, 512, 1>("32x32x16 row-wise 2x2 (4 per 4), 2 waves/SIMD", src, out, stamps, nblk);
+    run_pipe<7, 4, 512, -1>("row-wise, 7x4, 2 waves/SIMD", src, out, stamps, nblk);
+    run_pipe<4, 4, 512, -1>("row-wise, 4x4, 2 waves/SIMD", src, out, stamps, nblk);
+    run32<4, 2, 512, 1>("32x32x16 row-wise 4x2 again", src, out, stamps, nblk);
+    run<0>("registers only, 2 waves/SIMD again", src, out, stamps, nblk);
+    if (only32) return 0;
     run<1>("11 ds_read_b128 per 28 MFMAs, 2 waves/SIMD", src, out, stamps, nblk);
     run<0>("registers only (again)", src, out, stamps, nblk);
     run_pipe<7, 4, 512>("pipelined reads, 7x4 (11 per 28), 2 waves/SIMD", src, out, stamps, nblk);
