@@ -19,7 +19,9 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
+import traceback
 
 import torch
 
@@ -63,6 +65,13 @@ def parse():
                          "(B=64 x T=16: full-chip persistent ConvGRU launches next to the collectives), reported under 'dp_train' / "
                          "'dp_train_b64'; auto = when more than one rank runs, so that the driver's N>1 command exercises the "
                          "collective path")
+    ap.add_argument('--rehearse', action='store_true',
+                    help="NOT a measurement: run the N>1 control flow on a ONE-GPU box -- gloo instead of RCCL, every rank on cuda:0, "
+                         "ConvGRU as per-timestep launches (persistent launches of several processes must not share a device); "
+                         "the line carries 'rehearsal': true.  tests/test_bench_gpu.py")
+    ap.add_argument('--probe-timeout', type=int, default=int(os.environ.get('RGP_BENCH_PROBE_TIMEOUT_S', '420')),
+                    help="seconds the N>1 data-parallel probes may take before rank 0 prints the headline line with "
+                         "'dp_probe_error' and the process exits 3 (a collective that never returns must not cost the measurement)")
     ap.add_argument('--dp-finetune-probe', choices=['auto', 'on', 'off'], default='auto',
                     help="also time BASELINE config 5's data-parallel JOINT training step at its per-GPU shape (16 clips x T=35: "
                          "C3D + cascade, the gradient leaving in nine buckets on a side stream under the backward) with and "
@@ -120,9 +129,11 @@ def main():
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product path has no CPU fallback)')
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = rdist.init(backend='nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
+    dist = rdist.init(backend='gloo' if args.rehearse else 'nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
     B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
 
     g = torch.Generator(device=dev)
@@ -130,11 +141,11 @@ def main():
     ft = None
     if args.workload == 'finetune':
         from recurrent_gaze_prediction_amd.finetune import EndToEndGaze
-        ft = EndToEndGaze(B, T, dtype=args.dtype, device=dev, max_windows=min(args.c3d_chunk, F), seed=1)
+        ft = EndToEndGaze(B, T, dtype=args.dtype, device=dev, max_windows=min(args.c3d_chunk, F), seed=1, per_step=args.rehearse)
         ft.attach_process_group(dist)
         head, c3d = ft.head, ft.c3d
     else:
-        head = GrcnEngine(B, T, dtype=args.dtype, save_for_backward=args.workload == 'train', device=dev)
+        head = GrcnEngine(B, T, dtype=args.dtype, save_for_backward=args.workload == 'train', device=dev, per_step=args.rehearse)
         head.set_weights(syn.grcn_params(1, T))
     logits = torch.empty(B, T, 49, 49, device=dev)
     probs = torch.empty_like(logits)
@@ -205,23 +216,7 @@ def main():
     else:
         assert torch.isfinite(probs).all(), 'non-finite saliency maps'
 
-    # ---- N > 1: the driver's one command must also exercise the collective path (inference has none): BASELINE config 4's
-    # training step at its per-GPU shape, after the headline timing, reported in extra keys
-    dp_train = dp_train_b64 = None
-    if args.dp_train_probe == 'on' or (args.dp_train_probe == 'auto' and world > 1):
-        dp_train = rdist.dp_train_probe(dist, dev, rank=rank, batch=8, n_steps=35, steps=max(5, args.steps), warmup=2, dtype=args.dtype)
-        # ... and at config 3's per-GPU shape (64 clips x T = 16): the persistent ConvGRU forward and BPTT launches then take
-        # all 256 CUs (one workgroup each), the one interaction with a live RCCL kernel no smaller shape shows; the probe
-        # reports whether a launch lost a member and fell back ('convgru_fallbacks', 0 expected: the library releases no
-        # gradient bucket ahead of a full-chip launch, include/rgp.h)
-        dp_train_b64 = rdist.dp_train_probe(dist, dev, rank=rank, batch=64, n_steps=16, steps=max(5, args.steps), warmup=2, dtype=args.dtype)
-    # ... and the one place the design overlaps communication with compute: config 5's joint step (122.7 MB of conv + head
-    # gradient buckets + the cascade's 216 MB), timed with and without the collectives
-    dp_finetune = None
-    if args.dp_finetune_probe == 'on' or (args.dp_finetune_probe == 'auto' and world > 1):
-        # (the headline's engines stay alive next to it: 25 GB + the probe's 45 GB of the 288 GB)
-        dp_finetune = rdist.dp_finetune_probe(dist, dev, rank=rank, batch=16, n_steps=35, steps=3, warmup=1, dtype=args.dtype)
-
+    out = {}
     if rank == 0:
         frames_total = world * F * args.steps
         value = frames_total / elapsed
@@ -315,22 +310,93 @@ def main():
             'stage_ms_per_step': {k: round(v[0] / args.steps, 4) for k, v in list(cprof.items()) + list(hprof.items())},
             'roofline': roofline,
         }
-        if dp_train is not None:
-            out['dp_train'] = dp_train
-            out['dp_train_b64'] = dp_train_b64
-        if dp_finetune is not None:
-            out['dp_finetune'] = dp_finetune
+        if args.rehearse:
+            out['rehearsal'] = True             # gloo, one device, per-step ConvGRU: control flow only, the numbers mean nothing
         if world == 1 and not args.no_cpu_baseline and args.workload in ('e2e', 'head'):
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
-        print(json.dumps(out))
+
+    # ---- N > 1: the driver's one command must also exercise the collective path (inference has none).  The probes run AFTER
+    # the headline is measured and assembled, under a watchdog: whatever happens in them -- an exception on this rank, a peer
+    # that died, a collective that never returns -- rank 0 still prints its ONE line (with 'dp_probe_error') and exits non-zero.
+    emitted = threading.Lock()
+    store = rdist.default_store() if dist is not None else None              # c10d's key-value store: a channel beside the collectives
+    done = threading.Event()
+
+    def emit(extra):
+        if rank == 0 and emitted.acquire(blocking=False):
+            out.update(extra)
+            print(json.dumps(out), flush=True)
+            if store is not None:
+                store.set('rgp_probe_emitted', '1')
+
+    def watchdog():
+        # a peer that failed says so through the store (its collectives will never complete); otherwise the deadline
+        t_end, why = time.monotonic() + args.probe_timeout, None
+        while not done.wait(1.0):
+            if store is not None and store.check(['rgp_probe_error']):
+                why = store.get('rgp_probe_error').decode()
+                break
+            if time.monotonic() > t_end:
+                why = 'the data-parallel probes did not finish within %d s' % args.probe_timeout
+                break
+        if why is not None:
+            emit({'dp_probe_error': why + ' (the headline in this line is complete)'})
+            sys.stderr.write('bench.py: rank %d gives up on the data-parallel probes: %s\n' % (rank, why))
+            sys.stderr.flush()
+            os._exit(3)
+
+    want_train = args.dp_train_probe == 'on' or (args.dp_train_probe == 'auto' and world > 1)
+    want_ft = args.dp_finetune_probe == 'on' or (args.dp_finetune_probe == 'auto' and world > 1)
+    probes, err = {}, None
+    if (want_train or want_ft) and world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        inject = os.environ.get('RGP_BENCH_INJECT_PROBE_FAULT', '')           # tests: 'raise:<rank>' / 'hang:<rank>'
+        if inject and world > 1 and int(inject.split(':')[1]) == rank:
+            if inject.startswith('hang'):
+                time.sleep(10 ** 6)
+            raise RuntimeError('injected probe fault')
+        if want_train:
+            # BASELINE config 4's training step at its per-GPU shape ...
+            probes['dp_train'] = rdist.dp_train_probe(dist, dev, rank=rank, batch=8, n_steps=35, steps=max(5, args.steps), warmup=2, dtype=args.dtype, per_step=args.rehearse)
+            # ... and at config 3's per-GPU shape (64 clips x T = 16): the persistent ConvGRU forward and BPTT launches then take
+            # all 256 CUs (one workgroup each), the one interaction with a live RCCL kernel no smaller shape shows; the probe
+            # reports whether a launch lost a member and fell back ('convgru_fallbacks', 0 expected: the library releases no
+            # gradient bucket ahead of a full-chip launch, include/rgp.h)
+            probes['dp_train_b64'] = rdist.dp_train_probe(dist, dev, rank=rank, batch=64, n_steps=16, steps=max(5, args.steps), warmup=2, dtype=args.dtype,
+                                                          per_step=args.rehearse)
+        if want_ft:
+            # ... and the one place the design overlaps communication with compute: config 5's joint step (122.7 MB of conv + head
+            # gradient buckets + the cascade's 216 MB), timed with and without the collectives
+            # (the headline's engines stay alive next to it: 25 GB + the probe's 45 GB of the 288 GB)
+            probes['dp_finetune'] = rdist.dp_finetune_probe(dist, dev, rank=rank, batch=16, n_steps=35, steps=3, warmup=1, dtype=args.dtype,
+                                                            per_step=args.rehearse)
+    except Exception as e:                                                   # noqa: BLE001 -- reported, then the process fails
+        err = '%s: %s' % (type(e).__name__, e)
+        traceback.print_exc()
+    if err is not None:
+        # the peers may be inside a collective this rank will never join: no further collective from here.  Rank 0 prints; any
+        # other rank tells rank 0 through the store and gives it a moment to print before the launcher tears the job down
+        msg = 'rank %d: %s' % (rank, err)
+        if rank == 0 or store is None:
+            emit(dict(probes, dp_probe_error=msg))
+        else:
+            store.set('rgp_probe_error', msg)
+            t_end = time.monotonic() + 30.0
+            while time.monotonic() < t_end and not store.check(['rgp_probe_emitted']):
+                time.sleep(0.5)
+        os._exit(4)
     if dist is not None:
         dist.barrier()
+    done.set()
+    emit(probes)
+    if dist is not None:
         dist.destroy_process_group()
-    for probe in (dp_train, dp_train_b64, dp_finetune):
-        if probe is not None and (probe['ranks_seen'] != args.gpus or not probe['replicas_in_sync']):
-            raise SystemExit('bench.py: a data-parallel probe saw %d ranks for --gpus %d (replicas in sync: %s)'
-                             % (probe['ranks_seen'], args.gpus, probe['replicas_in_sync']))
+    for name, probe in probes.items():
+        if probe['ranks_seen'] != args.gpus or not probe['replicas_in_sync']:
+            raise SystemExit('bench.py: %s saw %d ranks for --gpus %d (replicas in sync: %s)'
+                             % (name, probe['ranks_seen'], args.gpus, probe['replicas_in_sync']))
 
 
 if __name__ == '__main__':

@@ -76,6 +76,16 @@ def sum_over_ranks(dist, value, device='cpu'):
     return float(t.item())
 
 
+def default_store():
+    """The default process group's key-value store (c10d TCPStore / FileStore): a side channel that works while the
+    collectives are stuck.  None when it cannot be had (bench.py's watchdog then has its deadline only)."""
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        return _get_default_store()
+    except Exception:                                                      # noqa: BLE001 -- a private API: optional
+        return None
+
+
 def gather_over_ranks(dist, value, device='cpu'):
     """[value of rank 0, value of rank 1, ...] (python floats; one all-gather): which rank set the MAX."""
     if dist is None:

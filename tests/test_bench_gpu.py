@@ -41,3 +41,46 @@ def test_default_bench_line_keeps_the_contract(gpu):
     assert cb['kind'] in ('port', 'reference') and cb['unit'] == 'frames/s' and cb['cores'] >= 1 and cb['value'] > 0 and cb['sample']
     # the stage timers of the library cover the step
     assert abs(sum(d['stage_ms_per_step'].values()) - d['ms_per_step']) < 0.05 * d['ms_per_step']
+
+
+def _rehearse(extra_env, extra_args=(), timeout=900):
+    """`bench.py --gpus 2 --rehearse`: the driver's N > 1 control flow (spawned ranks, barrier + MAX over ranks, per-rank
+    times, the three data-parallel probes, ONE line from rank 0) with gloo and both ranks on this GPU.  Small headline shape:
+    the numbers mean nothing."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update(extra_env)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse', '--steps', '2', '--warmup', '1',
+           '--batch', '4', '--n-steps', '4'] + list(extra_args)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    return r, lines
+
+
+def test_two_rank_rehearsal_prints_one_line_with_per_rank_times_and_all_three_probes(gpu):
+    r, lines = _rehearse({})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rehearsal'] is True and 'dp_probe_error' not in d
+    assert len(d['per_rank_ms']) == 2 and abs(max(d['per_rank_ms']) - d['ms_per_step']) < 1e-3
+    # whole-job value: both ranks' frames over the MAX of their times
+    assert abs(d['value'] - 2 * 16 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+    assert 'cpu_baseline' not in d                                            # rank 0 at N = 1 only
+    for key in ('dp_train', 'dp_train_b64', 'dp_finetune'):
+        p = d[key]
+        assert p['ranks_seen'] == 2 and p['replicas_in_sync'] is True and len(p['per_rank_ms']) == 2, (key, p)
+        assert p['convgru_fallbacks'] == 0, (key, p)
+    assert d['dp_train_b64']['convgru'] == 'per-step launches'                        # the rehearsal's plans, said so in the line
+
+
+@pytest.mark.parametrize('fault,rc', [('raise:1', 3), ('raise:0', 4), ('hang:1', 3)])
+def test_a_failing_probe_does_not_cost_the_headline(gpu, fault, rc):
+    """Whatever happens in the N > 1 probes -- a peer raises (rank 0 hears of it through the c10d store), rank 0 raises, a peer
+    never arrives (deadline) -- rank 0 prints its one line, with the complete headline and 'dp_probe_error', and the job fails."""
+    r, lines = _rehearse({'RGP_BENCH_INJECT_PROBE_FAULT': fault}, ('--probe-timeout', '25'), timeout=600)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert len(lines) == 1, (lines, r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['roofline']['frac'] > 0 and len(d['per_rank_ms']) == 2
+    want = 'did not finish within 25 s' if fault.startswith('hang') else 'rank %s: RuntimeError: injected probe fault' % fault[-1]
+    assert want in d['dp_probe_error'], d['dp_probe_error']
