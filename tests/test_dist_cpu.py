@@ -131,8 +131,11 @@ class TimedOut(object):
 lost = [rdist.engine_timeouts_all_ranks(d, TimedOut(world > 1 and rank == world - 1), 'cpu'),
         rdist.engine_timeouts_all_ranks(d, TimedOut(False), 'cpu')]
 clocks = rdist.gather_over_ranks(d, 10.0 + rank)
-print(json.dumps({'rank': rank, 'world': world, 'W': eng.flat_params.tolist(), 'norms': norms, 'flip_seed': seed,
-                  'bytes': red.bytes_reduced, 'buckets': red.buckets_reduced, 'agree': agree, 'lost': lost, 'clocks': clocks}), flush=True)
+# (ONE write per rank: print() emits the text and the newline separately, and two ranks share this pipe)
+sys.stdout.write(json.dumps({'rank': rank, 'world': world, 'W': eng.flat_params.tolist(), 'norms': norms, 'flip_seed': seed,
+                             'bytes': red.bytes_reduced, 'buckets': red.buckets_reduced, 'agree': agree, 'lost': lost,
+                             'clocks': clocks}) + '\n')
+sys.stdout.flush()
 if d is not None:
     d.barrier(); d.destroy_process_group()
 ''' % ROOT
