@@ -357,7 +357,7 @@ template <int BM, int BN> struct IgemmSmem {
 // Cin*sizeof(T) >= 128 B; 2/4 when a 128-B chunk spans several taps).
 // P = rows per pooling window (1, 4 or 8), rows of a window are consecutive in m.
 template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p, const EpiParams e) {
+__device__ __forceinline__ void igemm_tile(const IgemmParams& p, const EpiParams& e) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
   constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8 + NW - 1) / NW;
@@ -545,6 +545,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
     }
     __syncthreads();
   }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p, const EpiParams e) {
+  igemm_tile<T, BM, BN, WM, WN, G, P, Epi>(p, e);
+}
+
+// Several problems of one tile shape in one launch (blockIdx.z = problem; the transposed convolution's sub-pixel phases:
+// 49 GEMMs of 215 tiles each, which one by one leave CUs idle and pay 49 launch latencies).  Parameters come from device
+// arrays; blocks beyond a problem's own tile count leave at once.
+template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_grouped_kernel(const IgemmParams* __restrict__ ps, const EpiParams* __restrict__ es) {
+  const IgemmParams p = ps[blockIdx.z];
+  if ((int)blockIdx.x >= ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN)) return;
+  const EpiParams e = es[blockIdx.z];
+  igemm_tile<T, BM, BN, WM, WN, G, P, Epi>(p, e);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

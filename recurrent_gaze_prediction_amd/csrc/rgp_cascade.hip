@@ -164,17 +164,22 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
   const int B = g->B, T_ = g->T, F = g->F;
   constexpr int G16 = sizeof(T) == 2 ? 4 : 2;      // 16-channel taps per 128-byte chunk
   rgp_stream_t rs = (rgp_stream_t)s;
-  // (1) frame saliency, (2) bottom level
-  RGP_TRY(rgp_shallownet_forward(g->shallow, frames, F, (float*)(ws + g->sal), nullptr, rs));
+  // (1) frame saliency -- on the plan's side stream: nothing below reads it before put_saliency_kernel -- (2) bottom level
+  hipStream_t sc = s;
+  RGP_TRY(g->fork(s, 0, &sc));
+  RGP_TRY(rgp_shallownet_forward(g->shallow, frames, F, (float*)(ws + g->sal), nullptr, (rgp_stream_t)sc));
   RGP_TRY(rgp_proj_fwd(g->bottom, c3d_input, rs));
   RGP_TRY(rgp_convgru_xconv_fwd(g->bottom, rs));
   RGP_TRY(rgp_convgru_seq_fwd(g->bottom, rs));
   // (3) 7x7x256 -> 49x49x64 into channels 0..63 of the top cell's input; saliency into channel 64
-  for (const ConvDesc& d : g->up) {
-    IgemmParams p = make_params(d, g->bottom->ws + g->bottom->hbn.off, ws, F);
-    EpiParams e = make_epi(d, ws + g->xtopbuf, ws);
-    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
+  //     (49 sub-pixel phases, 215 tiles each: one grouped launch -- one by one they cost 49 x 24 us at 16 x 35)
+  if (dev_knob("RGP_CASCADE_GROUPED", 1)) {
+    RGP_TRY((launch_igemm_grouped<T, 1, 1, EpiStore<T, false, false>>(g->up_p, (const IgemmParams*)(ws + g->up_p_off),
+                                                                       (const EpiParams*)(ws + g->up_e_off), s)));
+  } else {
+    for (size_t i = 0; i < g->up.size(); ++i) RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(g->up_p[i], g->up_e[i], s)));
   }
+  if (sc != s) RGP_TRY(g->join(s));
   {
     const long long tot = (long long)F * 2401;
     put_saliency_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>((const float*)(ws + g->sal),
@@ -306,6 +311,8 @@ int rgp_cascade_create_ex(rgp_cascade_t** plan, int batch, int n_steps, int imag
   g->off_bottom = a.take(rgp_grcn_workspace_bytes(g->bottom));
   g->off_shallow = a.take(rgp_shallownet_workspace_bytes(g->shallow));
   for (ConvDesc& d : g->up) d.reserve(a, dtype);
+  g->up_p_off = a.take(g->up.size() * sizeof(IgemmParams));
+  g->up_e_off = a.take(g->up.size() * sizeof(EpiParams));
   for (ConvDesc* d : {&g->xtop, &g->zr, &g->c, &g->fc1, &g->fc2}) d->reserve(a, dtype);
   g->o_pad53_t = a.take(g->tab_pad53_t.size() * 4);
   g->o_pad53_x = a.take(g->tab_pad53_x.size() * 4);
@@ -355,6 +362,13 @@ int rgp_cascade_bind_workspace(rgp_cascade_t* g, void* workspace, size_t bytes, 
   RGP_TRY(rgp_grcn_bind_workspace(g->bottom, g->ws + g->off_bottom, rgp_grcn_workspace_bytes(g->bottom), stream));
   RGP_TRY(rgp_shallownet_bind_workspace(g->shallow, g->ws + g->off_shallow, rgp_shallownet_workspace_bytes(g->shallow), stream));
   for (ConvDesc& d : g->up) RGP_TRY(upload_desc(d, g->ws, s));
+  g->up_p.clear(); g->up_e.clear();
+  for (const ConvDesc& d : g->up) {
+    g->up_p.push_back(make_params(d, g->bottom->ws + g->bottom->hbn.off, g->ws, g->F));
+    g->up_e.push_back(make_epi(d, g->ws + g->xtopbuf, g->ws));
+  }
+  RGP_HIP(hipMemcpyAsync(g->ws + g->up_p_off, g->up_p.data(), g->up_p.size() * sizeof(IgemmParams), hipMemcpyHostToDevice, s));
+  RGP_HIP(hipMemcpyAsync(g->ws + g->up_e_off, g->up_e.data(), g->up_e.size() * sizeof(EpiParams), hipMemcpyHostToDevice, s));
   for (ConvDesc* d : {&g->xtop, &g->zr, &g->c, &g->fc1, &g->fc2}) RGP_TRY(upload_desc(*d, g->ws, s));
   RGP_HIP(hipMemcpyAsync(g->ws + g->o_pad53_t, g->tab_pad53_t.data(), g->tab_pad53_t.size() * 4, hipMemcpyHostToDevice, s));
   RGP_HIP(hipMemcpyAsync(g->ws + g->o_pad53_x, g->tab_pad53_x.data(), g->tab_pad53_x.size() * 4, hipMemcpyHostToDevice, s));

@@ -148,7 +148,9 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
                                                                  Tp(g->dz2), (long long)F * 2401);
   fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, s>>>(Tp(g->dz2), F, (float*)gr->fc2_b);
   RGP_HIP(hipGetLastError());
-  auto fc_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, size_t dz, float* dW, int k_valid) -> int {
+  // weight gradients run on the plan's side stream (rgp_cascade_plan.h): fork(i) behind the kernels that complete their operands
+  hipStream_t sw = s;
+  auto fc_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, size_t dz, float* dW, int k_valid, hipStream_t s) -> int {
     RGP_HIP(hipMemsetAsync(dW, 0, (size_t)k_valid * 4802 * 4, s));
     WgradParams p;
     memset(&p, 0, sizeof(p));
@@ -159,7 +161,8 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     p.M = F; p.N = 4802; p.nk = fwd.nk; p.ldw = 4802; p.k_valid = k_valid;
     return launch_wgrad<T, 1>(p, s);
   };
-  RGP_TRY(fc_wgrad(ws + g->mo1, g->K2, g->fc2, g->dz2, (float*)gr->fc2_w, 2401));
+  RGP_TRY(g->fork(s, 0, &sw));
+  RGP_TRY(fc_wgrad(ws + g->mo1, g->K2, g->fc2, g->dz2, (float*)gr->fc2_w, 2401, sw));
   {
     IgemmParams p = make_params(g->b_fc2, Tp(g->dz2) + kN2, ws, F);
     EpiParams e = make_epi(g->b_fc2, Fp(g->dmo1), ws);
@@ -170,7 +173,8 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
                                                                  Tp(g->dz1), (long long)F * 2401);
   fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, s>>>(Tp(g->dz1), F, (float*)gr->fc1_b);
   RGP_HIP(hipGetLastError());
-  RGP_TRY(fc_wgrad(ws + g->fcin, g->Kfc, g->fc1, g->dz1, (float*)gr->fc1_w, 7203));
+  RGP_TRY(g->fork(s, 1, &sw));
+  RGP_TRY(fc_wgrad(ws + g->fcin, g->Kfc, g->fc1, g->dz1, (float*)gr->fc1_w, 7203, sw));
   {
     IgemmParams p = make_params(g->b_fc1, Tp(g->dz1) + kN2, ws, F);
     EpiParams e = make_epi(g->b_fc1, Fp(g->dfcin), ws);
@@ -199,8 +203,10 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
       RGP_TRY((launch_igemm<T, G32, 1, EpiAccumF32>(p, e, s)));
     }
   }
-  // ---- top cell: filter gradients over all steps at once
+  // ---- top cell: filter gradients over all steps at once (side stream: beside the chain below)
   {
+    RGP_TRY(g->fork(s, 2, &sw));
+    hipStream_t s = sw;
     const long long img64 = kImg * 64, img16 = kImg * kSt;
     WgradParams p;
     memset(&p, 0, sizeof(p));
@@ -244,7 +250,8 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
   }
   // ---- stride-7 transposed conv: filter gradient dF[a,b,o,c] = sum dUp[7i+a-2, 7j+b-2, o] y[i,j,c], input gradient
   {
-    RGP_HIP(hipMemsetAsync((void*)gr->upsampling_weight, 0, (size_t)121 * 64 * 256 * 4, s));
+    RGP_TRY(g->fork(s, 3, &sw));
+    RGP_HIP(hipMemsetAsync((void*)gr->upsampling_weight, 0, (size_t)121 * 64 * 256 * 4, sw));
     WgradParams p;
     memset(&p, 0, sizeof(p));
     p.X = Tp(g->dup_pad); p.dY = g->bottom->ws + g->bottom->hbn.off; p.dW = (float*)gr->upsampling_weight;
@@ -253,7 +260,7 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     p.y_sx = 256; p.y_sy = 9 * 256; p.y_org = 10 * 256; p.y_img_stride = 81LL * 256;
     p.koff = (const int*)(ws + g->b_up.koff_off);
     p.M = (long long)F * 49; p.N = 256; p.nk = g->b_up.nk; p.ldw = 256; p.k_valid = 121 * 64;
-    RGP_TRY((launch_wgrad<T, 1>(p, s)));
+    RGP_TRY((launch_wgrad<T, 1>(p, sw)));
     IgemmParams q = make_params(g->b_up, Tp(g->dup_pad), ws, F);
     EpiParams e = make_epi(g->b_up, Fp(g->d_hbn), ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(q, e, s)));
@@ -275,6 +282,7 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     RGP_TRY(rgp_grcn_backward_from_states(g->bottom, Fp(g->d_hbn), &bg, (rgp_stream_t)s));
     if (d_rows) RGP_TRY(rgp_grcn_backward_input(g->bottom, d_rows, (rgp_stream_t)s));
   }
+  if (sw != s) RGP_TRY(g->join(s));
   return RGP_OK;
 }
 

@@ -14,6 +14,11 @@ struct rgp_cascade {
   rgp_grcn* bottom = nullptr;
   rgp_shallownet_t* shallow = nullptr;
   std::vector<rgp::ConvDesc> up;             // 49 phases of the stride-7 transposed conv
+  // ... run as ONE grouped launch: their kernel parameters, built at bind time (host copies outlive the upload), and the
+  // device arrays igemm_grouped_kernel reads
+  std::vector<rgp::IgemmParams> up_p;
+  std::vector<rgp::EpiParams> up_e;
+  size_t up_p_off = 0, up_e_off = 0;
   rgp::ConvDesc xtop, zr, c, fc1, fc2;
   std::vector<int> tab_pad53_t, tab_pad53_x;   // interior of a 53x53xkSt / 53x53xkCt image
   size_t o_pad53_t = 0, o_pad53_x = 0;
@@ -48,6 +53,43 @@ struct rgp_cascade {
   size_t d_hbn = 0;          // fp32 [F][49][256]: gradient w.r.t. the bottom states
   size_t dwx = 0, dwh = 0, dwu = 0;   // fp32 scratch of the top cell's filter gradients in packed K order
   size_t scratch_head = 0;   // fp32: dummy head / batch-norm gradients of the bottom sub-plan
+
+  // A stream of the plan's own for work the main chain does not wait for.  Forward: the frame saliency (ShallowNet, its own
+  // inputs) beside the projection and the bottom level's 35 per-step launches.  Backward: every weight gradient (the two FC
+  // layers, the top cell's three, the stride-7 filter) beside the data-gradient chain, whose BPTT loops are per-step launches
+  // on a fraction of the CUs.  ev[i]: "the operands of side task i are complete" on the caller's stream; ev_join: the side
+  // stream has drained.  Also recorded into a stream capture when the side stream exists already.
+  hipStream_t side = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+  // the side stream (made on first use) behind everything queued on s, or s itself when a capture of s finds none yet
+  int fork(hipStream_t s, int i, hipStream_t* sc) {
+    using namespace rgp;
+    *sc = s;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
+    if ((capturing && !side) || !rgp::dev_knob("RGP_CASCADE_FORK", 1)) return RGP_OK;
+    if (!side) {
+      RGP_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for (hipEvent_t* e : {&ev[0], &ev[1], &ev[2], &ev[3], &ev_join}) RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    RGP_HIP(hipEventRecord(ev[i], s));
+    RGP_HIP(hipStreamWaitEvent(side, ev[i], 0));
+    *sc = side;
+    return RGP_OK;
+  }
+  int join(hipStream_t s) {
+    using namespace rgp;
+    if (!side) return RGP_OK;
+    RGP_HIP(hipEventRecord(ev_join, side));
+    RGP_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    return RGP_OK;
+  }
+  ~rgp_cascade() {
+    if (side) {
+      (void)hipStreamDestroy(side);
+      for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
+    }
+  }
 };
 
 // rgp_cascade_bwd.hip

@@ -417,6 +417,29 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
   }
 }
 
+// n problems in one launch (igemm_grouped_kernel): dev_p / dev_e are device copies of ps / es.  Tile by the widest N as
+// launch_igemm's last three cases (the persistent kernels walk one problem's tile list).
+template <typename T, int G, int P, class Epi>
+int launch_igemm_grouped(const std::vector<IgemmParams>& ps, const IgemmParams* dev_p, const EpiParams* dev_e, hipStream_t s) {
+  if (ps.empty()) return RGP_OK;
+  int n_max = 0;
+  for (const IgemmParams& p : ps) {
+    if (p.M <= 0 || p.nk <= 0) return set_err(RGP_EINVAL, "igemm: empty problem M=%d nk=%d", p.M, p.nk);
+    n_max = std::max(n_max, p.N);
+  }
+  auto go = [&](auto kern, int BM, int BN, int threads, int smem) -> int {
+    RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
+    int tiles = 0;
+    for (const IgemmParams& p : ps) tiles = std::max(tiles, ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
+    kern<<<dim3(tiles, 1, (unsigned)ps.size()), dim3(threads), smem, s>>>(dev_p, dev_e);
+    RGP_HIP(hipGetLastError());
+    return RGP_OK;
+  };
+  if (n_max > 64) return go(igemm_grouped_kernel<T, 128, 128, 2, 2, G, P, Epi>, 128, 128, 256, IgemmSmem<128, 128>::BYTES);
+  if (n_max > 32) return go(igemm_grouped_kernel<T, 128, 64, 2, 2, G, P, Epi>, 128, 64, 256, IgemmSmem<128, 64>::BYTES);
+  return go(igemm_grouped_kernel<T, 128, 32, 4, 1, G, P, Epi>, 128, 32, 256, IgemmSmem<128, 32>::BYTES);
+}
+
 inline IgemmParams make_params(const ConvDesc& d, const void* A, char* ws, int n_img) {
   IgemmParams p;
   p.A = A;

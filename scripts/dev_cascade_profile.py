@@ -13,7 +13,17 @@ eng.set_weights(syn.cascade_params(0))
 frames = torch.rand(B, T, 98, 98, 3, device=dev)
 c3d = torch.tensor(syn.c3d_features(1, B, T), device=dev)
 gt = torch.rand(B, T, 49, 49, device=dev)
+import time
 for _ in range(10):
     eng.backward(eng.forward(frames, c3d), gt, want_d_rows=True)
 torch.cuda.synchronize()
-print('done')
+t0 = time.perf_counter()
+for _ in range(20):
+    eng.forward(frames, c3d)
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+for _ in range(20):
+    eng.backward(eng.forward(frames, c3d), gt, want_d_rows=True)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('cascade 16 x 35: forward %.3f ms, forward + backward %.3f ms' % ((t1 - t0) * 50, (t2 - t1) * 50))
