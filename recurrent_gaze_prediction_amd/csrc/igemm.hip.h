@@ -556,10 +556,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p,
 // 49 GEMMs of 215 tiles each, which one by one leave CUs idle and pay 49 launch latencies).  Parameters come from device
 // arrays; blocks beyond a problem's own tile count leave at once.
 template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_grouped_kernel(const IgemmParams* __restrict__ ps, const EpiParams* __restrict__ es) {
-  const IgemmParams p = ps[blockIdx.z];
+__global__ __launch_bounds__(WM* WN * 64) void igemm_grouped_kernel(const IgemmParams* __restrict__ ps, const EpiParams* __restrict__ es,
+                                                                    long long a_bytes, long long out_bytes) {
+  IgemmParams p = ps[blockIdx.z];
   if ((int)blockIdx.x >= ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN)) return;
-  const EpiParams e = es[blockIdx.z];
+  EpiParams e = es[blockIdx.z];
+  p.A = (const char*)p.A + a_bytes;              // the same problems on another slice of the operands (one time step)
+  e.out = (char*)e.out + out_bytes;
   igemm_tile<T, BM, BN, WM, WN, G, P, Epi>(p, e);
 }
 

@@ -77,12 +77,14 @@ bool conv5x5_desc(ConvDesc& d, int Cin, int N, long long ldc, int dtype) {
 
 // saliency map -> channel 64 of the top cell's halo-padded input image
 template <typename T>
-__global__ __launch_bounds__(256) void put_saliency_kernel(const float* __restrict__ sal, T* __restrict__ xtop, long long total) {
+// (frames f = j * f_mul + f_add, j < total / 2401: all of them, or the B frames of one time step)
+__global__ __launch_bounds__(256) void put_saliency_kernel(const float* __restrict__ sal, T* __restrict__ xtop, long long total, int f_mul,
+                                                           int f_add) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int p = (int)(i % 2401);
-    const long long f = i / 2401;
+    const long long f = (i / 2401) * f_mul + f_add;
     const int y = p / 49, x = p % 49;
-    xtop[(f * kHp * kHp + (y + 2) * kHp + x + 2) * kCt + 64] = Elem<T>::to(sal[i]);
+    xtop[(f * kHp * kHp + (y + 2) * kHp + x + 2) * kCt + 64] = Elem<T>::to(sal[f * 2401 + p]);
   }
 }
 
@@ -164,43 +166,75 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
   const int B = g->B, T_ = g->T, F = g->F;
   constexpr int G16 = sizeof(T) == 2 ? 4 : 2;      // 16-channel taps per 128-byte chunk
   rgp_stream_t rs = (rgp_stream_t)s;
-  // (1) frame saliency -- on the plan's side stream: nothing below reads it before put_saliency_kernel -- (2) bottom level
-  hipStream_t sc = s;
+  // Three chains, one time step apart (rgp_cascade_plan.h): `s` runs the bottom level, `sc` feeds the top cell (frame saliency
+  // first, then per step: the 49 upsampling phases, the saliency channel, the input convolution), `st` runs the top cell.
+  // Every link of each chain is a launch on a fraction of the CUs: together 35 x 49 us instead of 35 x (49 + 30) us plus the
+  // hoisted convolutions.  Inside a stream capture, or with RGP_CASCADE_PIPE=0 (dev), one chain with the hoisted forms.
+  hipStream_t sc = s, st2 = s;
   RGP_TRY(g->fork(s, 0, &sc));
+  // (the per-step events exist only where the bottom recurrence is per-step launches: S = 256 always is)
+  const bool pipe = sc != s && dev_knob("RGP_CASCADE_PIPE", 1) && g->bottom->seq_groups <= 0 && g->pipe_ok(s, T_);
+  if (pipe) {
+    st2 = g->side2;
+    RGP_HIP(hipStreamWaitEvent(st2, g->ev[0], 0));            // behind everything queued on s, as sc
+  }
   RGP_TRY(rgp_shallownet_forward(g->shallow, frames, F, (float*)(ws + g->sal), nullptr, (rgp_stream_t)sc));
-  RGP_TRY(rgp_proj_fwd(g->bottom, c3d_input, rs));
-  RGP_TRY(rgp_convgru_xconv_fwd(g->bottom, rs));
-  RGP_TRY(rgp_convgru_seq_fwd(g->bottom, rs));
+  g->bottom->step_ev = pipe ? g->ev_b.data() : nullptr;
+  int rc = rgp_proj_fwd(g->bottom, c3d_input, rs);
+  if (rc == RGP_OK) rc = rgp_convgru_xconv_fwd(g->bottom, rs);
+  if (rc == RGP_OK) rc = rgp_convgru_seq_fwd(g->bottom, rs);
+  g->bottom->step_ev = nullptr;
+  RGP_TRY(rc);
+  const int es_ = (int)sizeof(T);
+  const long long up_in_img = 81LL * 256, xtop_img = (long long)kHp * kHp * kCt, xpre_img = 2401LL * 3 * kSt;
   // (3) 7x7x256 -> 49x49x64 into channels 0..63 of the top cell's input; saliency into channel 64
   //     (49 sub-pixel phases, 215 tiles each: one grouped launch -- one by one they cost 49 x 24 us at 16 x 35)
-  if (dev_knob("RGP_CASCADE_GROUPED", 1)) {
-    RGP_TRY((launch_igemm_grouped<T, 1, 1, EpiStore<T, false, false>>(g->up_p, (const IgemmParams*)(ws + g->up_p_off),
-                                                                       (const EpiParams*)(ws + g->up_e_off), s)));
-  } else {
-    for (size_t i = 0; i < g->up.size(); ++i) RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(g->up_p[i], g->up_e[i], s)));
-  }
-  if (sc != s) RGP_TRY(g->join(s));
-  {
-    const long long tot = (long long)F * 2401;
-    put_saliency_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>((const float*)(ws + g->sal),
-                                                                                       (T*)(ws + g->xtopbuf), tot);
+  // (4) top cell: the x-part of its gates
+  auto feed = [&](int t, hipStream_t q) -> int {                // t < 0: every frame at once
+    const int n_img = t < 0 ? F : B;
+    const long long a_off = t < 0 ? 0 : t * up_in_img * es_, o_off = t < 0 ? 0 : t * xtop_img * es_;
+    if (dev_knob("RGP_CASCADE_GROUPED", 1)) {
+      RGP_TRY((launch_igemm_grouped<T, 1, 1, EpiStore<T, false, false>>(t < 0 ? g->up_p : g->up_p_step,
+                                                                         (const IgemmParams*)(ws + (t < 0 ? g->up_p_off : g->up_ps_off)),
+                                                                         (const EpiParams*)(ws + (t < 0 ? g->up_e_off : g->up_es_off)), q, a_off, o_off)));
+    } else {
+      for (size_t i = 0; i < g->up.size(); ++i) {
+        IgemmParams p = t < 0 ? g->up_p[i] : g->up_p_step[i];
+        EpiParams e = t < 0 ? g->up_e[i] : g->up_e_step[i];
+        p.A = (const char*)p.A + a_off;
+        e.out = (char*)e.out + o_off;
+        RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, q)));
+      }
+    }
+    const long long tot = (long long)n_img * 2401;
+    put_saliency_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, q>>>((const float*)(ws + g->sal), (T*)(ws + g->xtopbuf),
+                                                                                       tot, t < 0 ? 1 : T_, t < 0 ? 0 : t);
     RGP_HIP(hipGetLastError());
-  }
-  // (4) top cell: hoisted x-part, then T recurrent steps on 49x49
-  {
-    IgemmParams p = make_params(g->xtop, ws + g->xtopbuf, ws, F);
-    EpiParams e = make_epi(g->xtop, ws + g->xpre, ws);
-    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+    IgemmParams p = make_params(g->xtop, ws + g->xtopbuf + o_off, ws, n_img);
+    EpiParams e = make_epi(g->xtop, (float*)(ws + g->xpre) + (t < 0 ? 0 : t * xpre_img), ws);
+    if (t >= 0) { p.in_img_stride *= T_; e.out_img_stride *= T_; }
+    return launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, q);
+  };
+  if (!pipe) {
+    if (sc != s) RGP_TRY(g->join(s));
+    RGP_TRY(feed(-1, s));
   }
   const size_t st = (size_t)B * 2401 * kSt;
   const long long img16 = (long long)kHp * kHp * kSt;
   // inference: two state snapshots and one operand image per role; training: every step's states, gates and
   // operand images are kept (hp_all slot (b, t) = h_{t-1} of step t, slot (b, 0) is never written = h_0 = 0)
   const bool save = g->save;
-  if (!save) RGP_HIP(hipMemsetAsync(ws + g->hp, 0, (size_t)B * img16 * sizeof(T), s));
+  if (!save) RGP_HIP(hipMemsetAsync(ws + g->hp, 0, (size_t)B * img16 * sizeof(T), st2));
   float* hall = (float*)(ws + (save ? g->hall_t : g->hall));
-  RGP_HIP(hipMemsetAsync(hall, 0, st * 4, s));
+  RGP_HIP(hipMemsetAsync(hall, 0, st * 4, st2));
   for (int t = 0; t < T_; ++t) {
+    if (pipe) {
+      RGP_HIP(hipStreamWaitEvent(sc, g->ev_b[t], 0));           // the bottom state of step t
+      RGP_TRY(feed(t, sc));
+      RGP_HIP(hipEventRecord(g->ev_x[t], sc));
+      RGP_HIP(hipStreamWaitEvent(st2, g->ev_x[t], 0));          // the x-part of step t's gates
+    }
+    hipStream_t s = st2;
     char* hp_in = save ? ws + g->hp_all + (size_t)t * img16 * sizeof(T) : ws + g->hp;
     char* hp_out = save ? ws + g->hp_all + (size_t)(t + 1) * img16 * sizeof(T) : ws + g->hp;
     char* rh_buf = save ? ws + g->rhp_all + (size_t)t * img16 * sizeof(T) : ws + g->rh;
@@ -236,6 +270,11 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
     IgemmParams pc = make_params(g->c, rh_buf, ws, B);
     pc.in_img_stride = rh_stride;
     RGP_TRY((launch_igemm<T, G16, 1, EpiGruC<T>>(pc, e, s)));
+  }
+  if (pipe) {
+    RGP_HIP(hipEventRecord(g->ev_join2, st2));
+    RGP_HIP(hipStreamWaitEvent(s, g->ev_join2, 0));
+    RGP_TRY(g->join(s));
   }
   // (5) flatten + two maxout FCs
   {
@@ -313,6 +352,8 @@ int rgp_cascade_create_ex(rgp_cascade_t** plan, int batch, int n_steps, int imag
   for (ConvDesc& d : g->up) d.reserve(a, dtype);
   g->up_p_off = a.take(g->up.size() * sizeof(IgemmParams));
   g->up_e_off = a.take(g->up.size() * sizeof(EpiParams));
+  g->up_ps_off = a.take(g->up.size() * sizeof(IgemmParams));
+  g->up_es_off = a.take(g->up.size() * sizeof(EpiParams));
   for (ConvDesc* d : {&g->xtop, &g->zr, &g->c, &g->fc1, &g->fc2}) d->reserve(a, dtype);
   g->o_pad53_t = a.take(g->tab_pad53_t.size() * 4);
   g->o_pad53_x = a.take(g->tab_pad53_x.size() * 4);
@@ -367,8 +408,14 @@ int rgp_cascade_bind_workspace(rgp_cascade_t* g, void* workspace, size_t bytes, 
     g->up_p.push_back(make_params(d, g->bottom->ws + g->bottom->hbn.off, g->ws, g->F));
     g->up_e.push_back(make_epi(d, g->ws + g->xtopbuf, g->ws));
   }
-  RGP_HIP(hipMemcpyAsync(g->ws + g->up_p_off, g->up_p.data(), g->up_p.size() * sizeof(IgemmParams), hipMemcpyHostToDevice, s));
-  RGP_HIP(hipMemcpyAsync(g->ws + g->up_e_off, g->up_e.data(), g->up_e.size() * sizeof(EpiParams), hipMemcpyHostToDevice, s));
+  g->up_p_step = g->up_p; g->up_e_step = g->up_e;                       // the B frames of one step: image stride x T
+  for (IgemmParams& p : g->up_p_step) { p.M = p.Mw * g->B; p.in_img_stride *= g->T; }
+  for (EpiParams& e : g->up_e_step) e.out_img_stride *= g->T;
+  const size_t np = g->up_p.size() * sizeof(IgemmParams), ne = g->up_e.size() * sizeof(EpiParams);
+  RGP_HIP(hipMemcpyAsync(g->ws + g->up_p_off, g->up_p.data(), np, hipMemcpyHostToDevice, s));
+  RGP_HIP(hipMemcpyAsync(g->ws + g->up_e_off, g->up_e.data(), ne, hipMemcpyHostToDevice, s));
+  RGP_HIP(hipMemcpyAsync(g->ws + g->up_ps_off, g->up_p_step.data(), np, hipMemcpyHostToDevice, s));
+  RGP_HIP(hipMemcpyAsync(g->ws + g->up_es_off, g->up_e_step.data(), ne, hipMemcpyHostToDevice, s));
   for (ConvDesc* d : {&g->xtop, &g->zr, &g->c, &g->fc1, &g->fc2}) RGP_TRY(upload_desc(*d, g->ws, s));
   RGP_HIP(hipMemcpyAsync(g->ws + g->o_pad53_t, g->tab_pad53_t.data(), g->tab_pad53_t.size() * 4, hipMemcpyHostToDevice, s));
   RGP_HIP(hipMemcpyAsync(g->ws + g->o_pad53_x, g->tab_pad53_x.data(), g->tab_pad53_x.size() * 4, hipMemcpyHostToDevice, s));

@@ -16,9 +16,9 @@ struct rgp_cascade {
   std::vector<rgp::ConvDesc> up;             // 49 phases of the stride-7 transposed conv
   // ... run as ONE grouped launch: their kernel parameters, built at bind time (host copies outlive the upload), and the
   // device arrays igemm_grouped_kernel reads
-  std::vector<rgp::IgemmParams> up_p;
-  std::vector<rgp::EpiParams> up_e;
-  size_t up_p_off = 0, up_e_off = 0;
+  std::vector<rgp::IgemmParams> up_p, up_p_step;       // all frames at once / the B frames of one time step (image stride x T)
+  std::vector<rgp::EpiParams> up_e, up_e_step;
+  size_t up_p_off = 0, up_e_off = 0, up_ps_off = 0, up_es_off = 0;
   rgp::ConvDesc xtop, zr, c, fc1, fc2;
   std::vector<int> tab_pad53_t, tab_pad53_x;   // interior of a 53x53xkSt / 53x53xkCt image
   size_t o_pad53_t = 0, o_pad53_x = 0;
@@ -61,6 +61,12 @@ struct rgp_cascade {
   // stream has drained.  Also recorded into a stream capture when the side stream exists already.
   hipStream_t side = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+  // Forward as three chains that advance together, one time step apart (rgp_cascade.hip forward_impl): the bottom cell's T steps
+  // on the caller's stream (ev_b[t] behind step t), upsampling + saliency + the top cell's input convolution of step t on `side`
+  // (ev_x[t]), the top cell's step t on `side2`.  All three are per-step launches on a fraction of the CUs.
+  hipStream_t side2 = nullptr;
+  std::vector<hipEvent_t> ev_b, ev_x;
+  hipEvent_t ev_join2 = nullptr;
   // the side stream (made on first use) behind everything queued on s, or s itself when a capture of s finds none yet
   int fork(hipStream_t s, int i, hipStream_t* sc) {
     using namespace rgp;
@@ -77,6 +83,22 @@ struct rgp_cascade {
     *sc = side;
     return RGP_OK;
   }
+  // second side stream + per-step events (made on first use; not inside a stream capture)
+  bool pipe_ok(hipStream_t s, int n_steps) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)) return false;
+    if (!side2) {
+      if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess) { side2 = nullptr; return false; }
+      bool ok = hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < 2 * n_steps && ok; ++i) {
+        hipEvent_t e = nullptr;
+        ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) (i < n_steps ? ev_b : ev_x).push_back(e);
+      }
+      if (!ok) return false;
+    }
+    return (int)ev_b.size() == n_steps && (int)ev_x.size() == n_steps;
+  }
   int join(hipStream_t s) {
     using namespace rgp;
     if (!side) return RGP_OK;
@@ -88,6 +110,12 @@ struct rgp_cascade {
     if (side) {
       (void)hipStreamDestroy(side);
       for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
+    }
+    if (side2) {
+      (void)hipStreamDestroy(side2);
+      for (hipEvent_t e : ev_b) (void)hipEventDestroy(e);
+      for (hipEvent_t e : ev_x) (void)hipEventDestroy(e);
+      (void)hipEventDestroy(ev_join2);
     }
   }
 };

@@ -224,6 +224,7 @@ int seq_impl(rgp_grcn* g, hipStream_t s) {
     e.bn_inv_std = 1.0f / sqrtf(1.0f + 1e-3f);  // moving mean 0 / var 1, eps 1e-3
     IgemmParams pc = make_params(g->gc, g->ws + g->rhp.off, g->ws, B);
     RGP_TRY((launch_igemm<T, 1, 1, EpiGruC<T>>(pc, e, s)));
+    if (g->step_ev) RGP_HIP(hipEventRecord(g->step_ev[t], s));
   }
   return RGP_OK;
 }

@@ -420,7 +420,8 @@ int launch_igemm(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ks
 // n problems in one launch (igemm_grouped_kernel): dev_p / dev_e are device copies of ps / es.  Tile by the widest N as
 // launch_igemm's last three cases (the persistent kernels walk one problem's tile list).
 template <typename T, int G, int P, class Epi>
-int launch_igemm_grouped(const std::vector<IgemmParams>& ps, const IgemmParams* dev_p, const EpiParams* dev_e, hipStream_t s) {
+int launch_igemm_grouped(const std::vector<IgemmParams>& ps, const IgemmParams* dev_p, const EpiParams* dev_e, hipStream_t s,
+                         long long a_bytes = 0, long long out_bytes = 0) {
   if (ps.empty()) return RGP_OK;
   int n_max = 0;
   for (const IgemmParams& p : ps) {
@@ -431,7 +432,7 @@ int launch_igemm_grouped(const std::vector<IgemmParams>& ps, const IgemmParams* 
     RGP_TRY(ensure_dyn_smem((const void*)kern, smem));
     int tiles = 0;
     for (const IgemmParams& p : ps) tiles = std::max(tiles, ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
-    kern<<<dim3(tiles, 1, (unsigned)ps.size()), dim3(threads), smem, s>>>(dev_p, dev_e);
+    kern<<<dim3(tiles, 1, (unsigned)ps.size()), dim3(threads), smem, s>>>(dev_p, dev_e, a_bytes, out_bytes);
     RGP_HIP(hipGetLastError());
     return RGP_OK;
   };
