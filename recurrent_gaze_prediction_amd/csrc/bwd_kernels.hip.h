@@ -250,12 +250,13 @@ __global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__
                                                        const float* __restrict__ h_prev, const float* __restrict__ u,
                                                        const float* __restrict__ c, float* __restrict__ dxpre,
                                                        T* __restrict__ dcp_pad, const int* __restrict__ pad_tab, int B,
-                                                       int T_, int t, int S, int first) {
+                                                       int T_, int t, int S, int first, float* __restrict__ drh_zero) {
   const long long total = (long long)B * 49 * S;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int ch = (int)(i % S);
     const int p = (int)((i / S) % 49);
     const int b = (int)(i / ((long long)S * 49));
+    if (drh_zero) drh_zero[i] = 0.f;                  // the split-K U dgrad that follows adds its partial sums with atomics
     const float dh = dh_head[i] + (first ? 0.f : dh_carry[i]);
     const float uu = u[i], cc = c[i];
     const float du = dh * (h_prev[i] - cc), dc = dh * (1.f - uu);

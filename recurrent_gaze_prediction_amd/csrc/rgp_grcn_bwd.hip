@@ -338,16 +338,24 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   }
   if (fork) RGP_HIP(hipStreamWaitEvent(s, b->ev_join, 0));              // the chain has ended (it had the whole BPTT launch to do so)
   if (mark && !top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], s));     // full-chip launch: the TOP group leaves behind it
+  // Per-step BPTT (plans without the persistent launch: fp32, the cascade's 256-channel bottom cell, the fall-back).  A step is
+  // four dependent launches; its two dgrad convolutions have B x 49 rows -- a few dozen 64 x 64 tiles, each walking the whole
+  // K = 9 S / 18 S alone: split K over 2 / 3 blocks that add their partial sums with float atomics (drh zeroed by part 1,
+  // the carry holds part 1's term already).  16 x 35, S = 256: 23.9 + 42.5 us -> see profiles/r05_ab_cascade.txt
+  const int ks_c = std::max(1, std::min(4, dev_knob("RGP_BPTT_KSPLIT_C", b->b_c.nk >= 16 ? 2 : 1)));
+  const int ks_zr = std::max(1, std::min(4, dev_knob("RGP_BPTT_KSPLIT_ZR", b->b_zr.nk >= 48 ? 3 : b->b_zr.nk >= 16 ? 2 : 1)));
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
     gru_bwd1_kernel<T><<<ew_blocks, 256, 0, s>>>(Fp(b->dh_head) + (size_t)t * st, Fp(b->dh_carry), h_prev,
                                                   Fp(g->uall) + (size_t)t * st, Fp(g->call) + (size_t)t * st, Fp(b->dxpre),
-                                                  Tp(b->dcp_pad), I(g->o_pad9_S), B, T_, t, S, t == T_ - 1);
+                                                  Tp(b->dcp_pad), I(g->o_pad9_S), B, T_, t, S, t == T_ - 1,
+                                                  ks_c > 1 ? Fp(b->drh) : nullptr);
     RGP_HIP(hipGetLastError());
     {
       IgemmParams p = make_params(b->b_c, Tp(b->dcp_pad), ws, B);
       EpiParams e = make_epi(b->b_c, Fp(b->drh), ws);
-      RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
+      if (ks_c > 1) RGP_TRY((launch_igemm<T, 1, 1, EpiAtomicAddF32>(p, e, s, ks_c)));
+      else RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
     }
     gru_bwd2_kernel<T><<<ew_blocks, 256, 0, s>>>(Fp(b->drh), Fp(b->dh_carry), h_prev, Fp(g->rall) + (size_t)t * st,
                                                   Fp(b->dxpre), Tp(b->dzr_pad), I(b->o_pad2S), B, T_, t, S);
@@ -355,7 +363,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     {
       IgemmParams p = make_params(b->b_zr, Tp(b->dzr_pad), ws, B);
       EpiParams e = make_epi(b->b_zr, Fp(b->dh_carry), ws);
-      RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
+      if (ks_zr > 1) RGP_TRY((launch_igemm<T, 1, 1, EpiAtomicAddF32>(p, e, s, ks_zr)));
+      else RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
     }
   }
   // 7. hoisted input convs: the padded gradient image both branches below read

@@ -337,7 +337,7 @@ IgemmTile igemm_tile_choice(const IgemmParams& p, int ksplit) {
   // blocks of 128x128, so more of the 256 CUs have a tile
   {
     const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (ksplit == 1 && p.N >= 64 && tiles128 * ksplit < 160) return TILE_64x64;
+    if (p.N >= 64 && tiles128 * ksplit < 160) return TILE_64x64;
   }
   if (p.N > 64) return TILE_128x128;
   if (p.N > 32) return TILE_128x64;
