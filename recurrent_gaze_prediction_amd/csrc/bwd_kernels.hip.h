@@ -212,9 +212,9 @@ static __global__ __launch_bounds__(256) void head_unfold_grads_kernel(const flo
 static __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ hall,
                                                      const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dh_head, int B,
-                                                     int T_, int S, float inv) {
+                                                     int T_, int S, float inv, int t0) {
   __shared__ float sh[4];
-  const int t = blockIdx.y, c0 = blockIdx.x * 8;
+  const int t = blockIdx.y + t0, c0 = blockIdx.x * 8;      // (grid.y = T, t0 = 0: every step; grid.y = 1: step t0)
   float sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int rows = B * 49;
   for (int r = threadIdx.x; r < rows; r += 256) {

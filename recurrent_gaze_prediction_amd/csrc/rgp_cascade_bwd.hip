@@ -181,10 +181,38 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
   }
 
-  // ---- top cell: BPTT
+  // ---- top cell BPTT -> input gradient -> stride-7 transposed convolution -> bottom cell BPTT.  Three chains one time step
+  // apart (rgp_cascade_plan.h) when the plan has its streams: each chain is per-step launches on a fraction of the CUs.
+  const bool pipe = sw != s && dev_knob("RGP_CASCADE_PIPE", 1) && g->bottom->seq_groups <= 0 && g->pipe_ok(s, T_);
+  hipStream_t sa = s, sb = s;                                   // top cell BPTT / its input gradient down to the bottom states
+  if (pipe) {
+    sa = g->side2; sb = g->side3;
+    RGP_HIP(hipEventRecord(g->ev_join2, s));                     // d fc input is complete; nothing of an earlier call is in flight
+    RGP_HIP(hipStreamWaitEvent(sa, g->ev_join2, 0));
+    RGP_HIP(hipStreamWaitEvent(sb, g->ev_join2, 0));
+    RGP_HIP(hipMemsetAsync(Fp(g->d_hbn), 0, (size_t)F * 49 * 256 * 4, sb));    // the split-K transposed-conv gradient adds into it
+  }
+  const long long img64 = kImg * 64;
+  // gradient w.r.t. the upsampled maps (input channels 0..63 of the top cell; channel 64 is the frozen saliency), then w.r.t.
+  // the bottom states: d y[i,j,c] = sum_{a,b,o} dUp[7i+a-2, 7j+b-2, o] F[a,b,o,c].  t < 0: all frames at once
+  auto feed_back = [&](int t, hipStream_t q) -> int {
+    const int n_img = t < 0 ? F : B;
+    const long long off = t < 0 ? 0 : t * img64;
+    IgemmParams p = make_params(g->b_tx, Tp(g->dxpre_pad) + off, ws, n_img);
+    EpiParams e = make_epi(g->b_tx, Tp(g->dup_pad) + off, ws);
+    if (t >= 0) { p.in_img_stride *= T_; e.out_img_stride *= T_; }
+    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, q)));
+    if (t < 0) return RGP_OK;                                    // (the hoisted form runs the filter gradient in between: below)
+    IgemmParams pu = make_params(g->b_up, Tp(g->dup_pad) + off, ws, n_img);
+    EpiParams eu = make_epi(g->b_up, Fp(g->d_hbn) + (long long)t * 49 * 256, ws);
+    pu.in_img_stride *= T_; eu.out_img_stride *= T_;
+    // B x 49 rows, K = 121 x 64: a dozen tiles walking 121 K-chunks each -- split K four ways, float atomics
+    return launch_igemm<T, 1, 1, EpiAtomicAddF32>(pu, eu, q, 4);
+  };
   const float* hall = Fp(g->hall_t);
   for (int t = T_ - 1; t >= 0; --t) {
     const float* h_prev = hall + (size_t)t * st;
+    hipStream_t s = sa;
     top_bwd1_kernel<T><<<nblk((long long)st), 256, 0, s>>>(Fp(g->dfcin), g->Kfc, Fp(g->dh_carry), h_prev, Fp(g->uall) + (size_t)t * st,
                                                           Fp(g->call) + (size_t)t * st, Tp(g->dxpre_pad), Tp(g->dcp_pad), B, T_, t,
                                                           t == T_ - 1);
@@ -202,12 +230,20 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
       EpiParams e = make_epi(g->b_tzr, Fp(g->dh_carry), ws);
       RGP_TRY((launch_igemm<T, G32, 1, EpiAccumF32>(p, e, s)));
     }
+    if (pipe) {
+      RGP_HIP(hipEventRecord(g->ev_b[t], sa));                  // frame (b, t) of dxpre_pad is complete
+      RGP_HIP(hipStreamWaitEvent(sb, g->ev_b[t], 0));
+      RGP_TRY(feed_back(t, sb));
+      RGP_HIP(hipEventRecord(g->ev_x[t], sb));                  // ... and of d_hbn: the bottom cell's step t may run
+    }
   }
+  if (!pipe) RGP_TRY(feed_back(-1, s));
   // ---- top cell: filter gradients over all steps at once (side stream: beside the chain below)
   {
-    RGP_TRY(g->fork(s, 2, &sw));
+    if (pipe) { RGP_HIP(hipStreamWaitEvent(g->side, g->ev_b[0], 0)); sw = g->side; }      // behind the last BPTT step
+    else RGP_TRY(g->fork(s, 2, &sw));
     hipStream_t s = sw;
-    const long long img64 = kImg * 64, img16 = kImg * kSt;
+    const long long img16 = kImg * kSt;
     WgradParams p;
     memset(&p, 0, sizeof(p));
     p.dY = Tp(g->dxpre_pad);
@@ -242,15 +278,11 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
                                                                      (float*)gr->top_Ur, (float*)gr->top_U);
     RGP_HIP(hipGetLastError());
   }
-  // ---- gradient w.r.t. the upsampled maps (input channels 0..63 of the top cell; channel 64 is the frozen saliency)
+  // ---- stride-7 transposed conv: filter gradient dF[a,b,o,c] = sum dUp[7i+a-2, 7j+b-2, o] y[i,j,c] (side stream); hoisted
+  // form: its input gradient
   {
-    IgemmParams p = make_params(g->b_tx, Tp(g->dxpre_pad), ws, F);
-    EpiParams e = make_epi(g->b_tx, Tp(g->dup_pad), ws);
-    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<T, false, false>>(p, e, s)));
-  }
-  // ---- stride-7 transposed conv: filter gradient dF[a,b,o,c] = sum dUp[7i+a-2, 7j+b-2, o] y[i,j,c], input gradient
-  {
-    RGP_TRY(g->fork(s, 3, &sw));
+    if (pipe) { RGP_HIP(hipStreamWaitEvent(g->side, g->ev_x[0], 0)); sw = g->side; }      // behind the last frame of dup_pad
+    else RGP_TRY(g->fork(s, 3, &sw));
     RGP_HIP(hipMemsetAsync((void*)gr->upsampling_weight, 0, (size_t)121 * 64 * 256 * 4, sw));
     WgradParams p;
     memset(&p, 0, sizeof(p));
@@ -261,9 +293,11 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     p.koff = (const int*)(ws + g->b_up.koff_off);
     p.M = (long long)F * 49; p.N = 256; p.nk = g->b_up.nk; p.ldw = 256; p.k_valid = 121 * 64;
     RGP_TRY((launch_wgrad<T, 1>(p, sw)));
-    IgemmParams q = make_params(g->b_up, Tp(g->dup_pad), ws, F);
-    EpiParams e = make_epi(g->b_up, Fp(g->d_hbn), ws);
-    RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(q, e, s)));
+    if (!pipe) {
+      IgemmParams q = make_params(g->b_up, Tp(g->dup_pad), ws, F);
+      EpiParams e = make_epi(g->b_up, Fp(g->d_hbn), ws);
+      RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(q, e, s)));
+    }
   }
   // ---- bottom cell + projection (and the conv stack's input gradient)
   {
@@ -279,7 +313,10 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     bg.up_weight3 = sc; sc += 49 * 12 * 32;
     bg.out_W = sc; sc += 16;
     bg.out_b = sc;
-    RGP_TRY(rgp_grcn_backward_from_states(g->bottom, Fp(g->d_hbn), &bg, (rgp_stream_t)s));
+    g->bottom->bwd_step_ev = pipe ? g->ev_x.data() : nullptr;   // step t of its BPTT waits for frame (b, t) of d_hbn
+    const int rc = rgp_grcn_backward_from_states(g->bottom, Fp(g->d_hbn), &bg, (rgp_stream_t)s);
+    g->bottom->bwd_step_ev = nullptr;
+    RGP_TRY(rc);
     if (d_rows) RGP_TRY(rgp_grcn_backward_input(g->bottom, d_rows, (rgp_stream_t)s));
   }
   if (sw != s) RGP_TRY(g->join(s));

@@ -64,7 +64,10 @@ struct rgp_cascade {
   // Forward as three chains that advance together, one time step apart (rgp_cascade.hip forward_impl): the bottom cell's T steps
   // on the caller's stream (ev_b[t] behind step t), upsampling + saliency + the top cell's input convolution of step t on `side`
   // (ev_x[t]), the top cell's step t on `side2`.  All three are per-step launches on a fraction of the CUs.
-  hipStream_t side2 = nullptr;
+  // Backward, the same way in reverse: the top cell's BPTT on `side2` (ev_b[t] behind step t), step t's input gradient through
+  // the input convolution and the stride-7 transposed convolution on `side3` (ev_x[t]), the bottom cell's BPTT on the caller's
+  // stream (waits for ev_x[t] before its step t: rgp_grcn::bwd_step_ev); `side` keeps the weight gradients.
+  hipStream_t side2 = nullptr, side3 = nullptr;
   std::vector<hipEvent_t> ev_b, ev_x;
   hipEvent_t ev_join2 = nullptr;
   // the side stream (made on first use) behind everything queued on s, or s itself when a capture of s finds none yet
@@ -89,7 +92,8 @@ struct rgp_cascade {
     if (!(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)) return false;
     if (!side2) {
       if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess) { side2 = nullptr; return false; }
-      bool ok = hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) == hipSuccess;
+      bool ok = hipStreamCreateWithFlags(&side3, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) == hipSuccess;
       for (int i = 0; i < 2 * n_steps && ok; ++i) {
         hipEvent_t e = nullptr;
         ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -97,7 +101,7 @@ struct rgp_cascade {
       }
       if (!ok) return false;
     }
-    return (int)ev_b.size() == n_steps && (int)ev_x.size() == n_steps;
+    return side3 && (int)ev_b.size() == n_steps && (int)ev_x.size() == n_steps;
   }
   int join(hipStream_t s) {
     using namespace rgp;
@@ -113,6 +117,7 @@ struct rgp_cascade {
     }
     if (side2) {
       (void)hipStreamDestroy(side2);
+      if (side3) (void)hipStreamDestroy(side3);
       for (hipEvent_t e : ev_b) (void)hipEventDestroy(e);
       for (hipEvent_t e : ev_x) (void)hipEventDestroy(e);
       (void)hipEventDestroy(ev_join2);

@@ -133,6 +133,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const bool mark = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone);
   // the folded head's chain rule on the plan's side stream.  While `s` is being captured the same fork / join is recorded into
   // the graph (two parallel branches) -- provided the side stream exists already: streams are not created during a capture
+  const bool persistent = sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1);
+  const bool stepwise = ext_dy && g->bwd_step_ev && !persistent && mark;
   const bool side_ok = (mark || b->side != nullptr) && dev_knob("RGP_BWD_FORK", 1);
   const bool fork = g->fold_head && !ext_dy && side_ok;
   const bool wfork = side_ok && dev_knob("RGP_BWD_FORK", 1) != 2;
@@ -170,7 +172,8 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   if (ext_dy) {
     // the gradient w.r.t. the (batch-normalised) states comes from outside (cascade: the stride-7
     // transposed conv above the bottom cell); the head of this plan is unused, its gradients are zero
-    RGP_HIP(hipMemcpyAsync(Fp(b->dy), ext_dy, (size_t)M * S * 4, hipMemcpyDeviceToDevice, s));
+    // (stepwise: frame (b, t) of ext_dy is complete only behind bwd_step_ev[t] -- read in place, step by step, below)
+    if (!stepwise) RGP_HIP(hipMemcpyAsync(Fp(b->dy), ext_dy, (size_t)M * S * 4, hipMemcpyDeviceToDevice, s));
     RGP_HIP(hipMemsetAsync((void*)gr->up_weight3, 0, (size_t)49 * 12 * 32 * 4, s));
     RGP_HIP(hipMemsetAsync((void*)gr->out_W, 0, 12 * 4, s));
     RGP_HIP(hipMemsetAsync((void*)gr->out_b, 0, 4, s));
@@ -275,18 +278,18 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   }  // !ext_dy
   // 5. per-timestep batch-norm
   const float inv = 1.0f / sqrtf(1.0f + 1e-3f);
-  bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(Fp(b->dy), Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma,
-                                                  (float*)gr->bn_beta, Fp(b->dh_head), B, T_, S, inv);
+  if (!stepwise)
+    bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(Fp(b->dy), Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma,
+                                                    (float*)gr->bn_beta, Fp(b->dh_head), B, T_, S, inv, 0);
   // 6. BPTT: t = T-1 .. 0 -- one persistent launch where the plan allows it (bf16, the reference cell, <= 64 clips)
   const int ew_blocks = (int)std::min<size_t>((st + 255) / 256, 4096);
-  const bool persistent = sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1);
   // bn_gamma/beta, up_weight1..3, out_W, out_b are final here.  Their event lets the host start the group's all-reduce on
   // another stream -- i.e. an RCCL kernel that runs NEXT TO the BPTT launch.  That launch needs all its workgroups resident
   // together, one per CU (157 KB of LDS each): a collective's workgroup that reaches a CU first keeps a member off it until
   // the collective ends, which takes as long as the slowest peer rank.  So the early release is for launches that leave CUs
   // free (config 4: 8 clips per GPU = 64 workgroups); a launch that needs more than n_cu - RGP_RCCL_CU_RESERVE CUs
   // releases the group only behind itself (include/rgp.h, rgp_grcn_wait_grads).
-  const bool top_early = !persistent || grads_top_early(g);
+  const bool top_early = (!persistent || grads_top_early(g)) && !stepwise;     // (stepwise: the batch-norm gradients end with the loop)
   // h_{t-1} and r . h_{t-1} of every step, halo-padded [t][b][9][9][S]: the recurrent filter gradients' X operand (step 8)
   bool h_rh_padded = false;
   auto pad_h_rh = [&](hipStream_t q) -> int {
@@ -337,7 +340,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_TRY(guard.commit());
   }
   if (fork) RGP_HIP(hipStreamWaitEvent(s, b->ev_join, 0));              // the chain has ended (it had the whole BPTT launch to do so)
-  if (mark && !top_early) RGP_HIP(hipEventRecord(b->grad_ev[0], s));     // full-chip launch: the TOP group leaves behind it
+  if (mark && !top_early && !stepwise) RGP_HIP(hipEventRecord(b->grad_ev[0], s));     // full-chip launch: the TOP group leaves behind it
   // Per-step BPTT (plans without the persistent launch: fp32, the cascade's 256-channel bottom cell, the fall-back).  A step is
   // four dependent launches; its two dgrad convolutions have B x 49 rows -- a few dozen 64 x 64 tiles, each walking the whole
   // K = 9 S / 18 S alone: split K over 2 / 3 blocks that add their partial sums with float atomics (drh zeroed by part 1,
@@ -346,6 +349,11 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const int ks_zr = std::max(1, std::min(4, dev_knob("RGP_BPTT_KSPLIT_ZR", b->b_zr.nk >= 48 ? 3 : b->b_zr.nk >= 16 ? 2 : 1)));
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
+    if (stepwise) {
+      RGP_HIP(hipStreamWaitEvent(s, g->bwd_step_ev[t], 0));
+      bn_bwd_kernel<<<dim3(S / 8, 1), 256, 0, s>>>(ext_dy, Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma, (float*)gr->bn_beta,
+                                                    Fp(b->dh_head), B, T_, S, inv, t);
+    }
     gru_bwd1_kernel<T><<<ew_blocks, 256, 0, s>>>(Fp(b->dh_head) + (size_t)t * st, Fp(b->dh_carry), h_prev,
                                                   Fp(g->uall) + (size_t)t * st, Fp(g->call) + (size_t)t * st, Fp(b->dxpre),
                                                   Tp(b->dcp_pad), I(g->o_pad9_S), B, T_, t, S, t == T_ - 1,
@@ -367,6 +375,7 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       else RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
     }
   }
+  if (mark && stepwise) RGP_HIP(hipEventRecord(b->grad_ev[0], s));       // the batch-norm gradients ended with the loop
   // 7. hoisted input convs: the padded gradient image both branches below read
   {
     const long long tot = (long long)F * 49 * 3 * S;

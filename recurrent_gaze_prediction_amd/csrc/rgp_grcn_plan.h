@@ -11,6 +11,10 @@ struct rgp_grcn {
   // (owner: a cascade plan) step_ev[t] is recorded on the launch stream behind step t of the per-timestep recurrence: lets
   // another stream consume state t while the later steps run (rgp_cascade.hip).  Null = nothing recorded
   hipEvent_t* step_ev = nullptr;
+  // (same owner) backward from external state gradients with per-timestep BPTT: the launch stream waits for bwd_step_ev[t]
+  // before step t reads frame (b, t) of the gradient -- its producer runs one step ahead on another stream.  Null = the whole
+  // gradient is complete when the call is made
+  hipEvent_t* bwd_step_ev = nullptr;
   int B = 0, T = 0, P = 0, S = 0, dtype = RGP_BF16, save = 0, F = 0;
   rgp::ConvDesc proj, proj_rows, xconv, gzr, gc, d3;
   rgp::ConvDesc d3t;   // the folded 7x7 conv as a row-Toeplitz GEMM: 16 output pixels of a row per GEMM row (d3: x = 48 only)
