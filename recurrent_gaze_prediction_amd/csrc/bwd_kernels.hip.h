@@ -250,14 +250,19 @@ __global__ __launch_bounds__(256) void gru_bwd1_kernel(const float* __restrict__
                                                        const float* __restrict__ h_prev, const float* __restrict__ u,
                                                        const float* __restrict__ c, float* __restrict__ dxpre,
                                                        T* __restrict__ dcp_pad, const int* __restrict__ pad_tab, int B,
-                                                       int T_, int t, int S, int first, float* __restrict__ drh_zero) {
+                                                       int T_, int t, int S, int first, float* __restrict__ drh_zero,
+                                                       const float* __restrict__ dy_frames, const float* __restrict__ gamma_t,
+                                                       float bn_inv) {
   const long long total = (long long)B * 49 * S;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int ch = (int)(i % S);
     const int p = (int)((i / S) % 49);
     const int b = (int)(i / ((long long)S * 49));
     if (drh_zero) drh_zero[i] = 0.f;                  // the split-K U dgrad that follows adds its partial sums with atomics
-    const float dh = dh_head[i] + (first ? 0.f : dh_carry[i]);
+    // dy_frames (stepwise backward from external state gradients, frame-major [b*T + t][49][S]): the batch-norm's input
+    // gradient of this step is taken here instead of from a bn_bwd pass over all steps
+    const float head = dy_frames ? dy_frames[(((long long)b * T_ + t) * 49 + p) * S + ch] * gamma_t[ch] * bn_inv : dh_head[i];
+    const float dh = head + (first ? 0.f : dh_carry[i]);
     const float uu = u[i], cc = c[i];
     const float du = dh * (h_prev[i] - cc), dc = dh * (1.f - uu);
     dh_carry[i] = dh * uu;

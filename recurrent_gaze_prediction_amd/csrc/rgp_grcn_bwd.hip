@@ -345,19 +345,18 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // four dependent launches; its two dgrad convolutions have B x 49 rows -- a few dozen 64 x 64 tiles, each walking the whole
   // K = 9 S / 18 S alone: split K over 2 / 3 blocks that add their partial sums with float atomics (drh zeroed by part 1,
   // the carry holds part 1's term already).  16 x 35, S = 256: 23.9 + 42.5 us -> see profiles/r05_ab_cascade.txt
-  const int ks_c = std::max(1, std::min(4, dev_knob("RGP_BPTT_KSPLIT_C", b->b_c.nk >= 16 ? 2 : 1)));
-  const int ks_zr = std::max(1, std::min(4, dev_knob("RGP_BPTT_KSPLIT_ZR", b->b_zr.nk >= 48 ? 3 : b->b_zr.nk >= 16 ? 2 : 1)));
+  // (more splits cost more in atomics than they save: S = 256 at 16 x 35, (c, zr) = (1,1) 9.55, (2,2) 9.35, (2,3) 9.35, (2,4) 9.70,
+  // (3,3) 9.68, (3,6) 10.2 ms per cascade forward + backward, profiles/r05_ab_cascade.txt)
+  const int ks_c = std::max(1, std::min(8, dev_knob("RGP_BPTT_KSPLIT_C", b->b_c.nk >= 16 ? 2 : 1)));
+  const int ks_zr = std::max(1, std::min(8, dev_knob("RGP_BPTT_KSPLIT_ZR", b->b_zr.nk >= 48 ? 3 : b->b_zr.nk >= 16 ? 2 : 1)));
   for (int t = T_ - 1; t >= 0 && !persistent; --t) {
     const float* h_prev = Fp(g->hall) + (size_t)t * st;
-    if (stepwise) {
-      RGP_HIP(hipStreamWaitEvent(s, g->bwd_step_ev[t], 0));
-      bn_bwd_kernel<<<dim3(S / 8, 1), 256, 0, s>>>(ext_dy, Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma, (float*)gr->bn_beta,
-                                                    Fp(b->dh_head), B, T_, S, inv, t);
-    }
+    if (stepwise) RGP_HIP(hipStreamWaitEvent(s, g->bwd_step_ev[t], 0));      // frame (b, t) of ext_dy is complete
     gru_bwd1_kernel<T><<<ew_blocks, 256, 0, s>>>(Fp(b->dh_head) + (size_t)t * st, Fp(b->dh_carry), h_prev,
                                                   Fp(g->uall) + (size_t)t * st, Fp(g->call) + (size_t)t * st, Fp(b->dxpre),
                                                   Tp(b->dcp_pad), I(g->o_pad9_S), B, T_, t, S, t == T_ - 1,
-                                                  ks_c > 1 ? Fp(b->drh) : nullptr);
+                                                  ks_c > 1 ? Fp(b->drh) : nullptr, stepwise ? ext_dy : nullptr,
+                                                  b->w.bn_gamma + (size_t)t * S, inv);
     RGP_HIP(hipGetLastError());
     {
       IgemmParams p = make_params(b->b_c, Tp(b->dcp_pad), ws, B);
@@ -375,7 +374,11 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
       else RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
     }
   }
-  if (mark && stepwise) RGP_HIP(hipEventRecord(b->grad_ev[0], s));       // the batch-norm gradients ended with the loop
+  if (stepwise) {                                                         // the batch-norm's own gradients, off the step chain
+    bn_bwd_kernel<<<dim3(S / 8, T_), 256, 0, s>>>(ext_dy, Fp(g->hall), b->w.bn_gamma, (float*)gr->bn_gamma, (float*)gr->bn_beta,
+                                                    Fp(b->dh_head), B, T_, S, inv, 0);
+    if (mark) RGP_HIP(hipEventRecord(b->grad_ev[0], s));
+  }
   // 7. hoisted input convs: the padded gradient image both branches below read
   {
     const long long tot = (long long)F * 49 * 3 * S;
