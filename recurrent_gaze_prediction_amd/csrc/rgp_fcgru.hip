@@ -31,6 +31,7 @@ struct rgp_fcgru {
   // training-time dropout on c3d_embedded (gaze_rnn.py:302-303): caller-owned keep bytes [F*49*32], null = off
   const unsigned char* drop_mask = nullptr;
   float drop_keep = 1.0f;
+  SideStream side;           // backward: the filter and bias gradients, beside the BPTT loop and the projection's input gradient
   // ---- training ----
   bool save = false;
   size_t hall_t = 0, uall = 0, rall = 0, call = 0;   // fp32 [T(+1)][B][np]
@@ -297,7 +298,7 @@ int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const f
   RGP_HIP(hipGetLastError());
   WgradParams wp;
   auto rows_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, const void* dY, int ldy, int y_col, int N, float* dW, int ldw,
-                        int k_valid) -> int {
+                        int k_valid, hipStream_t s) -> int {
     RGP_HIP(hipMemsetAsync(dW, 0, (size_t)k_valid * ldw * 4, s));
     memset(&wp, 0, sizeof(wp));
     wp.X = X; wp.dY = dY; wp.dW = dW;
@@ -307,7 +308,9 @@ int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const f
     wp.M = F; wp.N = N; wp.nk = fwd.nk; wp.ldw = ldw; wp.k_valid = k_valid;
     return launch_wgrad<T, 1>(wp, s);
   };
-  RGP_TRY(rows_wgrad(ws + g->hrows, np, g->out, ws + g->dzo, Gp, 0, G, (float*)gr->proj_out_W, G, n));
+  hipStream_t sw = s;                                           // the gradients' stream (SideStream, rgp_host.h)
+  RGP_TRY(g->side.fork(s, 0, &sw));
+  RGP_TRY(rows_wgrad(ws + g->hrows, np, g->out, ws + g->dzo, Gp, 0, G, (float*)gr->proj_out_W, G, n, sw));
   {
     IgemmParams p = make_params(g->b_out, Tp(g->dzo) + Gp, ws, F);
     EpiParams e = make_epi(g->b_out, Fp(g->dh_head), ws);
@@ -334,8 +337,12 @@ int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const f
       RGP_TRY((launch_igemm<T, 1, 1, EpiAccumF32>(p, e, s)));
     }
   }
-  // 3. kernel gradients, hoisted over all steps
-  RGP_TRY(rows_wgrad(ws + g->E, Kx, g->xg, ws + g->dxpre, 3 * np, 0, 3 * np, Fp(g->dwx), 3 * np, Kx));
+  // 3. kernel gradients, hoisted over all steps (side stream: beside step 4)
+  RGP_TRY(g->side.fork(s, 1, &sw));
+  const T* dx1 = Tp(g->dxpre) + 3 * np;
+  {
+  hipStream_t s = sw;
+  RGP_TRY(rows_wgrad(ws + g->E, Kx, g->xg, ws + g->dxpre, 3 * np, 0, 3 * np, Fp(g->dwx), 3 * np, Kx, s));
   {
     RGP_HIP(hipMemsetAsync(Fp(g->dwh), 0, (size_t)np * 2 * np * 4, s));
     memset(&wp, 0, sizeof(wp));
@@ -357,11 +364,11 @@ int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const f
   fc_unpack_kernel<<<nblk((long long)(nx + n) * n), 256, 0, s>>>(Fp(g->dwx), Fp(g->dwh), Fp(g->dwc), (float*)gr->gates_kernel,
                                                                (float*)gr->candidate_kernel, nx, n, np);
   // biases: gates_bias [r | u], candidate_bias
-  const T* dx1 = Tp(g->dxpre) + 3 * np;
   fc_colsum_kernel<T><<<(n + 15) / 16, 256, 0, s>>>(dx1 + np, 3LL * np, F, n, (float*)gr->gates_bias);
   fc_colsum_kernel<T><<<(n + 15) / 16, 256, 0, s>>>(dx1, 3LL * np, F, n, (float*)gr->gates_bias + n);
   fc_colsum_kernel<T><<<(n + 15) / 16, 256, 0, s>>>(dx1 + 2 * np, 3LL * np, F, n, (float*)gr->candidate_bias);
   RGP_HIP(hipGetLastError());
+  }
   // 4. projection: d E = dxpre Wx^T, then per-pixel rows [F*49][32]
   {
     IgemmParams p = make_params(g->b_x, dx1, ws, F);
@@ -381,6 +388,7 @@ int backward_impl(rgp_fcgru* g, const float* logits, const float* probs, const f
     RGP_TRY((launch_wgrad<T, 1>(wp, s)));
     // bias: sum over frames and pixels = column sums of the [F*49][32] view; rows are 32 apart inside a frame row
     // of Kx, so sum per frame-row column first: c3d_b[c] = sum_f sum_pix dE[f][pix*32 + c]
+    if (sw != s) RGP_TRY(g->side.join(s));                      // (dwc is the candidate filter's gradient until fc_unpack has read it)
     fc_colsum_kernel<T><<<(Kx + 15) / 16, 256, 0, s>>>(Tp(g->dE) + Kx, Kx, F, Kx, Fp(g->dwc));     // dwc reused as [Kx] scratch
     RGP_HIP(hipGetLastError());
   }

@@ -246,6 +246,40 @@ struct PackBatch {
   }
 };
 
+// A stream of a plan's own for work its main chain does not wait for (weight gradients beside the data-gradient chain ...):
+// fork(s, i, &sc) puts the side stream behind everything queued on s (event i) and hands it out -- or s itself while s is
+// being captured and the side stream does not exist yet; join(s) makes s wait for the side stream to drain.  Made on first use.
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+  int fork(hipStream_t s, int i, hipStream_t* sc) {
+    *sc = s;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
+    if ((capturing && !side) || !dev_knob("RGP_SIDE_STREAM", 1)) return RGP_OK;
+    if (!side) {
+      RGP_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for (hipEvent_t* e : {&ev[0], &ev[1], &ev[2], &ev[3], &ev_join}) RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    RGP_HIP(hipEventRecord(ev[i], s));
+    RGP_HIP(hipStreamWaitEvent(side, ev[i], 0));
+    *sc = side;
+    return RGP_OK;
+  }
+  int join(hipStream_t s) {
+    if (!side) return RGP_OK;
+    RGP_HIP(hipEventRecord(ev_join, side));
+    RGP_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    return RGP_OK;
+  }
+  ~SideStream() {
+    if (side) {
+      (void)hipStreamDestroy(side);
+      for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
+    }
+  }
+};
+
 // ---- launch dispatch -------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int G, int P, class Epi>
 int launch_cfg(const IgemmParams& p, const EpiParams& e, hipStream_t s, int ksplit = 1) {

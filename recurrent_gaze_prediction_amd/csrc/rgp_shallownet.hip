@@ -23,6 +23,7 @@ struct rgp_shallownet {
   size_t frames4 = 0, pool1 = 0, act2 = 0, pool2 = 0, act3 = 0, pool3 = 0, mo1 = 0, b1i = 0, b2i = 0;
   size_t ws_bytes = 0;
   char* ws = nullptr;
+  SideStream side;           // backward: filter and bias gradients beside the data-gradient chain
   bool weights_set = false;
   const float *b_conv1 = nullptr, *b_conv2 = nullptr, *b_conv3 = nullptr;
   // ---- training ----
@@ -328,7 +329,10 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   auto Fp = [&](size_t off) { return (float*)(ws + off); };
   auto nblk = [](long long x) { return (int)std::min<long long>((x + 255) / 256, 8192); };
   WgradParams wp;
-  auto fc_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, size_t dz, float* dW, int k_valid) -> int {
+  // filter and bias gradients run on the plan's side stream (SideStream, rgp_host.h) beside the data-gradient chain; the last
+  // layer's have nothing left to run beside and stay on s
+  hipStream_t sw = s;
+  auto fc_wgrad = [&](const void* X, int ldx, const ConvDesc& fwd, size_t dz, float* dW, int k_valid, hipStream_t s) -> int {
     RGP_HIP(hipMemsetAsync(dW, 0, (size_t)k_valid * 4802 * 4, s));
     memset(&wp, 0, sizeof(wp));
     wp.X = X; wp.dY = ws + dz; wp.dW = dW;
@@ -341,9 +345,10 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   // ---- fully connected read-out (saliency_shallownet.py:139-185)
   maxout_bwd_kernel<T><<<nblk((long long)n * 2401), 256, 0, s>>>(d_sal, 2401, nullptr, 1.0f, (const unsigned char*)(ws + g->mask2),
                                                                  Tp(g->dz2), (long long)n * 2401);
-  fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, s>>>(Tp(g->dz2), n, (float*)gr->fc2_b);
+  RGP_TRY(g->side.fork(s, 0, &sw));
+  fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, sw>>>(Tp(g->dz2), n, (float*)gr->fc2_b);
   RGP_HIP(hipGetLastError());
-  RGP_TRY(fc_wgrad(ws + g->mo1, g->K2, g->fc2, g->dz2, (float*)gr->fc2_w, 2401));
+  RGP_TRY(fc_wgrad(ws + g->mo1, g->K2, g->fc2, g->dz2, (float*)gr->fc2_w, 2401, sw));
   {
     IgemmParams p = make_params(g->b_fc2, Tp(g->dz2) + kFcN2, ws, n);
     EpiParams e = make_epi(g->b_fc2, Fp(g->dmo1), ws);
@@ -351,16 +356,18 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
   }
   maxout_bwd_kernel<T><<<nblk((long long)n * 2401), 256, 0, s>>>(Fp(g->dmo1), g->K2, nullptr, 1.0f, (const unsigned char*)(ws + g->mask1),
                                                                  Tp(g->dz1), (long long)n * 2401);
-  fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, s>>>(Tp(g->dz1), n, (float*)gr->fc1_b);
+  RGP_TRY(g->side.fork(s, 1, &sw));
+  fc_bias_grad_kernel<T><<<(4802 + 31) / 32, 256, 0, sw>>>(Tp(g->dz1), n, (float*)gr->fc1_b);
   RGP_HIP(hipGetLastError());
-  RGP_TRY(fc_wgrad(ws + g->pool3, g->Kf, g->fc1, g->dz1, (float*)gr->fc1_w, g->nflat));
+  RGP_TRY(fc_wgrad(ws + g->pool3, g->Kf, g->fc1, g->dz1, (float*)gr->fc1_w, g->nflat, sw));
   {
     IgemmParams p = make_params(g->b_fc1, Tp(g->dz1) + kFcN2, ws, n);
     EpiParams e = make_epi(g->b_fc1, Fp(g->dpool3), ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
   }
   // ---- conv3 (3x3 VALID 64 -> 32) behind pool3
-  auto conv_wgrad = [&](const void* X, int in_h, int Cin, const ConvDesc& fwd, size_t dy, int out_h, int Cout, float* dW, int G) -> int {
+  auto conv_wgrad = [&](const void* X, int in_h, int Cin, const ConvDesc& fwd, size_t dy, int out_h, int Cout, float* dW, int G,
+                        hipStream_t s) -> int {
     const int Wp = out_h + 4;
     RGP_HIP(hipMemsetAsync(dW, 0, (size_t)9 * Cin * Cout * 4, s));
     memset(&wp, 0, sizeof(wp));
@@ -376,11 +383,12 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
     const int H = g->c3, OH = g->p3, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
     maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 4), 256, 0, s>>>(Tp(g->act3), Fp(g->dpool3), g->Kf, Tp(g->dy3), n, H, 32, 3, 2,
                                                                               OH, pad, 2, (const unsigned char*)(ws + g->amax3));
-    RGP_HIP(hipMemsetAsync((void*)gr->conv3_b, 0, 32 * 4, s));
-    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 2), 1024), 256, 0, s>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, (long long)Wp * Wp * 32, H, Wp * 32,
+    RGP_TRY(g->side.fork(s, 2, &sw));
+    RGP_HIP(hipMemsetAsync((void*)gr->conv3_b, 0, 32 * 4, sw));
+    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 2), 1024), 256, 0, sw>>>(Tp(g->dy3) + (2 * Wp + 2) * 32, (long long)Wp * Wp * 32, H, Wp * 32,
                                                                            32, (long long)n * H * H, (float*)gr->conv3_b);
     RGP_HIP(hipGetLastError());
-    RGP_TRY(conv_wgrad(ws + g->pool2, g->p2, 64, g->conv3, g->dy3, H, 32, (float*)gr->conv3_w, 1));
+    RGP_TRY(conv_wgrad(ws + g->pool2, g->p2, 64, g->conv3, g->dy3, H, 32, (float*)gr->conv3_w, 1, sw));
     IgemmParams p = make_params(g->b_c3, Tp(g->dy3), ws, n);
     EpiParams e = make_epi(g->b_c3, Fp(g->dpool2), ws);
     RGP_TRY((launch_igemm<T, G32, 1, EpiStore<float, false, false>>(p, e, s)));
@@ -390,11 +398,12 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
     const int H = g->c2, OH = g->p2, pad = std::max((OH - 1) * 2 + 3 - H, 0) / 2, Wp = H + 4;
     maxpool_same_bwd_kernel<T><<<nblk((long long)n * H * H * 8), 256, 0, s>>>(Tp(g->act2), Fp(g->dpool2), (long long)OH * OH * 64, Tp(g->dy2),
                                                                               n, H, 64, 3, 2, OH, pad, 2, (const unsigned char*)(ws + g->amax2));
-    RGP_HIP(hipMemsetAsync((void*)gr->conv2_b, 0, 64 * 4, s));
-    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 4), 1024), 256, 0, s>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, (long long)Wp * Wp * 64, H, Wp * 64,
+    RGP_TRY(g->side.fork(s, 3, &sw));
+    RGP_HIP(hipMemsetAsync((void*)gr->conv2_b, 0, 64 * 4, sw));
+    conv_bias_grad_kernel<T><<<std::min(nblk((long long)n * H * H * 4), 1024), 256, 0, sw>>>(Tp(g->dy2) + (2 * Wp + 2) * 64, (long long)Wp * Wp * 64, H, Wp * 64,
                                                                            64, (long long)n * H * H, (float*)gr->conv2_b);
     RGP_HIP(hipGetLastError());
-    RGP_TRY(conv_wgrad(ws + g->pool1, g->p1, 32, g->conv2, g->dy2, H, 64, (float*)gr->conv2_w, G32));
+    RGP_TRY(conv_wgrad(ws + g->pool1, g->p1, 32, g->conv2, g->dy2, H, 64, (float*)gr->conv2_w, G32, sw));
     IgemmParams p = make_params(g->b_c2, Tp(g->dy2), ws, n);
     EpiParams e = make_epi(g->b_c2, Fp(g->dpool1), ws);
     RGP_TRY((launch_igemm<T, 1, 1, EpiStore<float, false, false>>(p, e, s)));
@@ -421,6 +430,7 @@ int backward_impl(rgp_shallownet* g, int n, const float* d_sal, const rgp_shallo
     conv1_unpack_grad_kernel<<<(5 * 5 * 3 * 32 + 255) / 256, 256, 0, s>>>(Fp(g->dw1), (float*)gr->conv1_w);
     RGP_HIP(hipGetLastError());
   }
+  if (sw != s) RGP_TRY(g->side.join(s));
   return RGP_OK;
 }
 
