@@ -204,3 +204,37 @@ def test_cascade_model_class(gpu, tmp_path):
     model.load_state_dict(state)
     out2 = model.predict(c3d, frames).cpu().numpy()
     assert np.abs(out2 - out).max() > 0.1
+
+
+@pytest.mark.parametrize('dtype,save', [('bf16', False), ('bf16', True), ('f32', False)])
+def test_three_chain_forward_is_bit_identical_to_the_one_chain_form(gpu, dtype, save):
+    """An eager forward runs the plan's three chains (bottom cell / per-step upsampling + input convolution / top cell, one time
+    step apart on three streams); the same call captured into a HIP graph takes the one-chain form with the hoisted
+    convolutions (no per-step events inside a capture).  Same GEMMs over a different partition of the rows: torch.equal --
+    an event or a slice offset wrong in either form shows up here at every stage."""
+    from recurrent_gaze_prediction_amd.engine import CascadeEngine
+    B, T = 3, 6
+    eng = CascadeEngine(B, T, 98, dtype=dtype, device=gpu, save_for_backward=save)
+    eng.set_weights(syn.cascade_params(41))
+    g = torch.Generator(device=gpu); g.manual_seed(5)
+    frames = torch.rand(B, T, 98, 98, 3, device=gpu, generator=g)
+    c3d = torch.tensor(syn.c3d_features(42, B, T), device=gpu)
+    eager = eng.forward(frames, c3d)
+    stages = {k: eng.read_buffer(k).clone() for k in eng.BUFFERS}
+    assert bool(torch.isfinite(eager).all()) and float(eager.abs().max()) > 0
+    s = torch.cuda.Stream(device=gpu)
+    s.wait_stream(torch.cuda.current_stream(gpu))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        eng.forward(frames, c3d)                               # (eager on the capture stream first)
+    torch.cuda.synchronize(gpu)
+    with torch.cuda.graph(graph, stream=s):
+        captured = eng.forward(frames, c3d)
+    captured.zero_()
+    graph.replay()
+    torch.cuda.synchronize(gpu)
+    assert torch.equal(captured, eager)
+    for k, v in stages.items():
+        assert torch.equal(eng.read_buffer(k), v), k
+    # ... and the eager form again afterwards (its events and streams were not disturbed by the capture)
+    assert torch.equal(eng.forward(frames, c3d), eager)
