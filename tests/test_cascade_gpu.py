@@ -238,3 +238,28 @@ def test_three_chain_forward_is_bit_identical_to_the_one_chain_form(gpu, dtype, 
         assert torch.equal(eng.read_buffer(k), v), k
     # ... and the eager form again afterwards (its events and streams were not disturbed by the capture)
     assert torch.equal(eng.forward(frames, c3d), eager)
+
+
+def test_three_chain_passes_are_repeatable(gpu):
+    """The plan's streams and per-step events under repetition: 25 training passes on the same inputs give the same maps bit for
+    bit and the same gradients up to the float-atomics' summation order (a missing dependency between the chains would show as
+    a pass that read a half-written frame)."""
+    from recurrent_gaze_prediction_amd.engine import CascadeEngine
+    B, T = 4, 9
+    eng = CascadeEngine(B, T, 98, dtype='bf16', device=gpu, save_for_backward=True)
+    eng.set_weights(syn.cascade_params(43))
+    g = torch.Generator(device=gpu); g.manual_seed(6)
+    frames = torch.rand(B, T, 98, 98, 3, device=gpu, generator=g)
+    c3d = torch.tensor(syn.c3d_features(44, B, T), device=gpu)
+    gt = torch.rand(B, T, 49, 49, device=gpu, generator=g)
+    maps0 = eng.forward(frames, c3d).clone()
+    _, d0 = eng.backward(maps0, gt, want_d_rows=True)
+    g0, d0 = eng.flat_grads.clone(), d0.clone()
+    scale_g, scale_d = float(g0.abs().max()), float(d0.abs().max())
+    assert scale_g > 0 and scale_d > 0
+    for _ in range(25):
+        maps = eng.forward(frames, c3d)
+        assert torch.equal(maps, maps0)
+        _, d = eng.backward(maps, gt, want_d_rows=True)
+        assert float((eng.flat_grads - g0).abs().max()) < 2e-4 * scale_g
+        assert float((d - d0).abs().max()) < 2e-3 * scale_d          # (bf16 rows behind fp32 atomics)
