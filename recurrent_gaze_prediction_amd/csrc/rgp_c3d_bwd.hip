@@ -240,8 +240,13 @@ int run_wgrad_patch(rgp_c3d* c, int layer, int n, float* dw, float* db, hipStrea
 }
 
 template <typename T>
-int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, float* grads, hipStream_t s) {
+int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, float* grads, hipStream_t s_in) {
   char* ws = c->ws;
+  hipStream_t s = s_in, sw = s_in;
+  // Layers whose filter gradient runs on the plan's side stream beside the input gradient (both read dYpre[i]).  The large
+  // layers' kernels are matrix-pipe bound and hold one block per CU: sharing the chip gains nothing there
+  // (profiles/r05_c3d_bwd_fork_experiment.txt); conv5a / conv5b's are one round of ingest-bound blocks.
+  const int fork_mask = sizeof(T) == 2 ? dev_knob("RGP_C3D_BWD_FORK", 0xC0) : 0;
   const int n = c->last_n;
   constexpr int G0 = sizeof(T) == 2 ? 4 : 2;
   auto blocks_for = [](long long items, int per_block) { return (int)std::min<long long>((items + per_block - 1) / per_block, 4096); };
@@ -256,6 +261,10 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     const C3dLayerSpec& l = kLayers[i];
     const C3dBwdLayer& b = c->B[i];
     const int Mw = l.D * l.H * l.H;
+    if ((fork_mask >> i) & 1) {
+      RGP_TRY(c->side.fork(s_in, i & 3, &sw));
+      s = sw;
+    }
     // filter gradient on the patch kernels (wgrad_patch.hip.h; dev builds: one mask bit per layer)?
     const bool wg_patch = sizeof(T) == 2 && c->use_patch() && i >= 1 && i <= 5 && ((dev_knob("RGP_WGPATCH", 31) >> (i - 1)) & 1);
     if (!pooled(i) && !wg_patch) {  // bias gradient (pooled layers: done by unpool below; patch kernels: with the filter gradient)
@@ -319,6 +328,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
     }
     // layer i's gradient slice (filter here; bias here or, pooled layers, in the un-pool of the step before) is queued
     if (c->grad_ev_made) RGP_HIP(hipEventRecord(c->grad_ev[i], s));
+    s = s_in;
     if (i == 0) break;
     // gradient w.r.t. the layer input = pooled (or plain) output of layer i-1
     const C3dBwdLayer& lo = c->B[i - 1];
@@ -365,6 +375,7 @@ int backward_impl(rgp_c3d* c, const float* d_features, const float* d_rows, floa
       RGP_TRY((launch_igemm<T, 1, 1, EpiStoreMask<T>>(p, e, s)));
     }
   }
+  if (sw != s_in) RGP_TRY(c->side.join(s_in));
   return RGP_OK;
 }
 

@@ -59,6 +59,8 @@ struct rgp_c3d {
   // start the all-reduce of that layer's slice on another stream while the earlier layers are still differentiating
   hipEvent_t grad_ev[8] = {nullptr};
   bool grad_ev_made = false;
+  // backward: conv5a's / conv5b's filter gradients (wgrad_kernel, one round of ingest-bound blocks) beside their input gradients
+  rgp::SideStream side;
   ~rgp_c3d() {
     if (grad_ev_made) for (int i = 0; i < 8; ++i) (void)hipEventDestroy(grad_ev[i]);
   }
