@@ -133,7 +133,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = rdist.init(backend='gloo' if args.rehearse else 'nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
+    control_note = None
+    try:
+        dist = rdist.init(backend='gloo' if args.rehearse else 'nccl', device=dev)      # 'nccl' is RCCL on ROCm; None when world == 1
+    except Exception as e:                                       # noqa: BLE001
+        # RCCL could not build its communicator (first N > 1 run on this pool): the headline has no data-path collective --
+        # gloo can carry its barrier, MAX and per-rank times; the probes, which exist to exercise RCCL, are skipped and say so
+        if args.rehearse or world == 1 or args.workload in ('train', 'finetune'):
+            raise
+        control_note = 'RCCL initialisation failed (%s: %s); gloo carries the barrier / MAX over ranks' % (type(e).__name__, str(e)[:300])
+        sys.stderr.write('bench.py: %s\n' % control_note)
+        dist = rdist.init(backend='gloo', device=dev)
     B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
 
     g = torch.Generator(device=dev)
@@ -348,6 +358,11 @@ def main():
 
     want_train = args.dp_train_probe == 'on' or (args.dp_train_probe == 'auto' and world > 1)
     want_ft = args.dp_finetune_probe == 'on' or (args.dp_finetune_probe == 'auto' and world > 1)
+    if control_note is not None:
+        want_train = want_ft = False
+        if rank == 0:
+            out['control_plane'] = control_note
+            out['dp_probe_error'] = 'skipped: ' + control_note
     probes, err = {}, None
     if (want_train or want_ft) and world > 1:
         threading.Thread(target=watchdog, daemon=True).start()
