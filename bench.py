@@ -143,6 +143,10 @@ def main():
             raise
         control_note = 'RCCL initialisation failed (%s: %s); gloo carries the barrier / MAX over ranks' % (type(e).__name__, str(e)[:300])
         sys.stderr.write('bench.py: %s\n' % control_note)
+        import torch.distributed as tdist
+        if tdist.is_initialized():                               # (a half-built default group)
+            tdist.destroy_process_group()
+        os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)   # the first store may still hold the port
         dist = rdist.init(backend='gloo', device=dev)
     B, T, F = args.batch, args.n_steps, args.batch * args.n_steps
 
