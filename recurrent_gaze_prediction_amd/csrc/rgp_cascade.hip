@@ -179,6 +179,14 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
     RGP_HIP(hipStreamWaitEvent(st2, g->ev[0], 0));            // behind everything queued on s, as sc
   }
   RGP_TRY(rgp_shallownet_forward(g->shallow, frames, F, (float*)(ws + g->sal), nullptr, (rgp_stream_t)sc));
+  // The feed chain is the longest of the three (three launches per step) and its steps do not depend on each other: odd
+  // steps go to the plan's third side stream, behind the frame saliency
+  hipStream_t sc_odd = sc;
+  if (pipe && dev_knob("RGP_CASCADE_FEED2", 1)) {
+    sc_odd = g->side3;
+    RGP_HIP(hipEventRecord(g->ev_join2, sc));
+    RGP_HIP(hipStreamWaitEvent(sc_odd, g->ev_join2, 0));
+  }
   g->bottom->step_ev = pipe ? g->ev_b.data() : nullptr;
   int rc = rgp_proj_fwd(g->bottom, c3d_input, rs);
   if (rc == RGP_OK) rc = rgp_convgru_xconv_fwd(g->bottom, rs);
@@ -229,9 +237,10 @@ int forward_impl(rgp_cascade* g, const float* frames, const float* c3d_input, fl
   RGP_HIP(hipMemsetAsync(hall, 0, st * 4, st2));
   for (int t = 0; t < T_; ++t) {
     if (pipe) {
-      RGP_HIP(hipStreamWaitEvent(sc, g->ev_b[t], 0));           // the bottom state of step t
-      RGP_TRY(feed(t, sc));
-      RGP_HIP(hipEventRecord(g->ev_x[t], sc));
+      hipStream_t sf = (t & 1) ? sc_odd : sc;
+      RGP_HIP(hipStreamWaitEvent(sf, g->ev_b[t], 0));           // the bottom state of step t
+      RGP_TRY(feed(t, sf));
+      RGP_HIP(hipEventRecord(g->ev_x[t], sf));
       RGP_HIP(hipStreamWaitEvent(st2, g->ev_x[t], 0));          // the x-part of step t's gates
     }
     hipStream_t s = st2;

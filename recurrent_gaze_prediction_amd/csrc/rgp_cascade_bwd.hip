@@ -209,6 +209,43 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
     // B x 49 rows, K = 121 x 64: a dozen tiles walking 121 K-chunks each -- split K four ways, float atomics
     return launch_igemm<T, 1, 1, EpiAtomicAddF32>(pu, eu, q, 4);
   };
+  // The top cell's filter gradients over the steps [t0, t0 + k): image = clip b, z = step.  Partial sums are added into the
+  // packed scratch with atomics, so chunks of steps accumulate (first: the scratch is cleared on the same stream).
+  constexpr int kWgChunk = 7;
+  auto top_wgrads = [&](int t0, int k, hipStream_t q, bool first) -> int {
+    const long long img16 = kImg * kSt, imgx = kImg * kCt;
+    if (first) {
+      RGP_HIP(hipMemsetAsync(Fp(g->dwx), 0, (size_t)g->xtop.nk * BKE * 48 * 4, q));
+      RGP_HIP(hipMemsetAsync(Fp(g->dwh), 0, (size_t)g->zr.nk * BKE * 32 * 4, q));
+      RGP_HIP(hipMemsetAsync(Fp(g->dwu), 0, (size_t)g->c.nk * BKE * 16 * 4, q));
+    }
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.dY = Tp(g->dxpre_pad) + (long long)t0 * img64;
+    p.y_sx = 64; p.y_sy = kHp * 64; p.y_sz = (int)img64; p.y_org = (2 * kHp + 2) * 64;
+    p.y_img_stride = (long long)T_ * img64;
+    wgrad_grid(p, k, 49, 49);
+    p.M = (long long)B * k * 2401;
+    // x part: X = the top cell's input images (128 channels), all three gates (48 columns)
+    p.X = Tp(g->xtopbuf) + (long long)t0 * imgx; p.dW = Fp(g->dwx);
+    p.x_sx = kCt; p.x_sy = kHp * kCt; p.x_sz = (int)imgx; p.x_img_stride = (long long)T_ * imgx;
+    p.koff = (const int*)(ws + g->xtop.koff_off);
+    p.N = 48; p.nk = g->xtop.nk; p.ldw = 48; p.k_valid = g->xtop.nk * BKE;
+    RGP_TRY((launch_wgrad<T, 1>(p, q)));
+    // h part, gates z and r: X = h_{t-1} images (slot (b, t))
+    p.X = Tp(g->hp_all) + (long long)t0 * img16; p.dW = Fp(g->dwh);
+    p.x_sx = kSt; p.x_sy = kHp * kSt; p.x_sz = (int)img16; p.x_img_stride = (long long)(T_ + 1) * img16;
+    p.koff = (const int*)(ws + g->zr.koff_off);
+    p.N = 32; p.nk = g->zr.nk; p.ldw = 32; p.k_valid = g->zr.nk * BKE;
+    RGP_TRY((launch_wgrad<T, G16>(p, q)));
+    // h part, candidate: X = r (.) h_{t-1} images, gradient columns [32, 48)
+    p.X = Tp(g->rhp_all) + (long long)t0 * img16; p.dW = Fp(g->dwu);
+    p.x_img_stride = (long long)T_ * img16;
+    p.y_org = (2 * kHp + 2) * 64 + 2 * kSt;
+    p.koff = (const int*)(ws + g->c.koff_off);
+    p.N = 16; p.nk = g->c.nk; p.ldw = 16; p.k_valid = g->c.nk * BKE;
+    return launch_wgrad<T, G16>(p, q);
+  };
   const float* hall = Fp(g->hall_t);
   for (int t = T_ - 1; t >= 0; --t) {
     const float* h_prev = hall + (size_t)t * st;
@@ -235,49 +272,25 @@ int backward_impl(rgp_cascade* g, const float* maps, const float* gt, const rgp_
       RGP_HIP(hipStreamWaitEvent(sb, g->ev_b[t], 0));
       RGP_TRY(feed_back(t, sb));
       RGP_HIP(hipEventRecord(g->ev_x[t], sb));                  // ... and of d_hbn: the bottom cell's step t may run
+      // the top cell's filter gradients of the steps [t, t + chunk) just differentiated: on the weight-gradient stream while
+      // the BPTT goes on (waiting for its last step with all of them put 1 ms of full-chip launches behind the chains)
+      if (t % kWgChunk == 0) {
+        RGP_HIP(hipStreamWaitEvent(g->side, g->ev_b[t], 0));
+        RGP_TRY(top_wgrads(t, std::min(kWgChunk, T_ - t), g->side, t + kWgChunk >= T_));
+      }
     }
   }
   if (!pipe) RGP_TRY(feed_back(-1, s));
-  // ---- top cell: filter gradients over all steps at once (side stream: beside the chain below)
-  {
-    if (pipe) { RGP_HIP(hipStreamWaitEvent(g->side, g->ev_b[0], 0)); sw = g->side; }      // behind the last BPTT step
-    else RGP_TRY(g->fork(s, 2, &sw));
-    hipStream_t s = sw;
-    const long long img16 = kImg * kSt;
-    WgradParams p;
-    memset(&p, 0, sizeof(p));
-    p.dY = Tp(g->dxpre_pad);
-    p.y_sx = 64; p.y_sy = kHp * 64; p.y_sz = (int)img64; p.y_org = (2 * kHp + 2) * 64;
-    // x part: X = the top cell's input images (128 channels), all three gates (48 columns)
-    RGP_HIP(hipMemsetAsync(Fp(g->dwx), 0, (size_t)g->xtop.nk * BKE * 48 * 4, s));
-    p.X = ws + g->xtopbuf; p.dW = Fp(g->dwx);
-    wgrad_grid(p, 1, 49, 49);
-    p.x_sx = kCt; p.x_sy = kHp * kCt; p.x_sz = 0; p.x_img_stride = kImg * kCt; p.y_img_stride = img64;
-    p.koff = (const int*)(ws + g->xtop.koff_off);
-    p.M = (long long)F * 2401; p.N = 48; p.nk = g->xtop.nk; p.ldw = 48; p.k_valid = g->xtop.nk * BKE;
-    RGP_TRY((launch_wgrad<T, 1>(p, s)));
-    // h part, gates z and r: X = h_{t-1} images; image = clip b, z = step t
-    RGP_HIP(hipMemsetAsync(Fp(g->dwh), 0, (size_t)g->zr.nk * BKE * 32 * 4, s));
-    p.X = ws + g->hp_all; p.dW = Fp(g->dwh);
-    wgrad_grid(p, T_, 49, 49);
-    p.x_sx = kSt; p.x_sy = kHp * kSt; p.x_sz = (int)img16; p.x_img_stride = (long long)(T_ + 1) * img16;
-    p.y_img_stride = (long long)T_ * img64;
-    p.koff = (const int*)(ws + g->zr.koff_off);
-    p.M = (long long)F * 2401; p.N = 32; p.nk = g->zr.nk; p.ldw = 32; p.k_valid = g->zr.nk * BKE;
-    RGP_TRY((launch_wgrad<T, G16>(p, s)));
-    // h part, candidate: X = r (.) h_{t-1} images, gradient columns [32, 48)
-    RGP_HIP(hipMemsetAsync(Fp(g->dwu), 0, (size_t)g->c.nk * BKE * 16 * 4, s));
-    p.X = ws + g->rhp_all; p.dW = Fp(g->dwu);
-    p.x_img_stride = (long long)T_ * img16;
-    p.y_org = (2 * kHp + 2) * 64 + 2 * kSt;
-    p.koff = (const int*)(ws + g->c.koff_off);
-    p.N = 16; p.nk = g->c.nk; p.ldw = 16; p.k_valid = g->c.nk * BKE;
-    RGP_TRY((launch_wgrad<T, G16>(p, s)));
-    top_unpack_grads_kernel<<<(25 * 65 * 3 + 255) / 256, 256, 0, s>>>(Fp(g->dwx), Fp(g->dwh), Fp(g->dwu), (float*)gr->top_Wz,
-                                                                     (float*)gr->top_Wr, (float*)gr->top_W, (float*)gr->top_Uz,
-                                                                     (float*)gr->top_Ur, (float*)gr->top_U);
-    RGP_HIP(hipGetLastError());
+  // ---- top cell: filter gradients (one-chain form: all steps at once, on the side stream beside the chain below)
+  if (pipe) sw = g->side;
+  else {
+    RGP_TRY(g->fork(s, 2, &sw));
+    RGP_TRY(top_wgrads(0, T_, sw, true));
   }
+  top_unpack_grads_kernel<<<(25 * 65 * 3 + 255) / 256, 256, 0, sw>>>(Fp(g->dwx), Fp(g->dwh), Fp(g->dwu), (float*)gr->top_Wz,
+                                                                    (float*)gr->top_Wr, (float*)gr->top_W, (float*)gr->top_Uz,
+                                                                    (float*)gr->top_Ur, (float*)gr->top_U);
+  RGP_HIP(hipGetLastError());
   // ---- stride-7 transposed conv: filter gradient dF[a,b,o,c] = sum dUp[7i+a-2, 7j+b-2, o] y[i,j,c] (side stream); hoisted
   // form: its input gradient
   {
