@@ -76,9 +76,10 @@ struct rgp_cascade {
     *sc = s;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
-    if ((capturing && !side) || !rgp::dev_knob("RGP_CASCADE_FORK", 1)) return RGP_OK;
-    if (!side) {
-      RGP_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (!rgp::dev_knob("RGP_CASCADE_FORK", 1)) return RGP_OK;
+    RGP_TRY(pool_stream(0, !capturing, &side));                 // the device's pool (rgp_core.hip): shared, not owned
+    if (!side) return RGP_OK;
+    if (!ev_join) {
       for (hipEvent_t* e : {&ev[0], &ev[1], &ev[2], &ev[3], &ev_join}) RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     RGP_HIP(hipEventRecord(ev[i], s));
@@ -90,10 +91,9 @@ struct rgp_cascade {
   bool pipe_ok(hipStream_t s, int n_steps) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (!(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)) return false;
-    if (!side2) {
-      if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) != hipSuccess) { side2 = nullptr; return false; }
-      bool ok = hipStreamCreateWithFlags(&side3, hipStreamNonBlocking) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) == hipSuccess;
+    if (!side2 || !side3 || !ev_join2) {
+      if (rgp::pool_stream(1, true, &side2) != RGP_OK || rgp::pool_stream(2, true, &side3) != RGP_OK || !side2 || !side3) return false;
+      bool ok = hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming) == hipSuccess;
       for (int i = 0; i < 2 * n_steps && ok; ++i) {
         hipEvent_t e = nullptr;
         ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -105,23 +105,16 @@ struct rgp_cascade {
   }
   int join(hipStream_t s) {
     using namespace rgp;
-    if (!side) return RGP_OK;
+    if (!side || !ev_join) return RGP_OK;
     RGP_HIP(hipEventRecord(ev_join, side));
     RGP_HIP(hipStreamWaitEvent(s, ev_join, 0));
     return RGP_OK;
   }
   ~rgp_cascade() {
-    if (side) {
-      (void)hipStreamDestroy(side);
-      for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
-    }
-    if (side2) {
-      (void)hipStreamDestroy(side2);
-      if (side3) (void)hipStreamDestroy(side3);
-      for (hipEvent_t e : ev_b) (void)hipEventDestroy(e);
-      for (hipEvent_t e : ev_x) (void)hipEventDestroy(e);
-      (void)hipEventDestroy(ev_join2);
-    }
+    if (ev_join) for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_b) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_x) (void)hipEventDestroy(e);
+    if (ev_join2) (void)hipEventDestroy(ev_join2);
   }
 };
 

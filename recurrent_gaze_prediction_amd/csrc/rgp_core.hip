@@ -39,6 +39,23 @@ int device_cu_count(int* n_cu) {
   return RGP_OK;
 }
 
+// Side streams: ONE pool of three per device for every plan of the process.  The runtime maps streams onto four hardware
+// queues in creation order; a plan that made streams of its own late in a process's life (the tenth plan of a benchmark
+// script, say) got queues that other streams already shared, and chains meant to run side by side ran one after the other
+// (profiles/r05_configs.json before / after).  Calls fork behind the caller's stream and join before they return, so plans
+// sharing the pool only ever delay each other.  Never destroyed.
+int pool_stream(int i, bool create, hipStream_t* out) {
+  static std::mutex mu;
+  static hipStream_t pool[64][3] = {};
+  int dev = 0;
+  RGP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || i < 0 || i >= 3) return set_err(RGP_EINVAL, "pool_stream: device %d, stream %d", dev, i);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool[dev][i] && create) RGP_HIP(hipStreamCreateWithFlags(&pool[dev][i], hipStreamNonBlocking));
+  *out = pool[dev][i];
+  return RGP_OK;
+}
+
 namespace {
 struct PersistentGuard {
   std::mutex mu;

@@ -48,8 +48,7 @@ struct GrcnBwd {
   hipEvent_t ev_fork = nullptr, ev_bn = nullptr, ev_join = nullptr, ev_wfork = nullptr, ev_wjoin = nullptr;
   ~GrcnBwd() {
     if (grad_ev_made) for (int i = 0; i < 3; ++i) (void)hipEventDestroy(grad_ev[i]);
-    if (side) {
-      (void)hipStreamDestroy(side);
+    if (ev_fork) {                                           // (the stream belongs to the device's pool)
       (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_bn); (void)hipEventDestroy(ev_join);
       (void)hipEventDestroy(ev_wfork); (void)hipEventDestroy(ev_wjoin);
     }
@@ -60,11 +59,13 @@ namespace {
 
 constexpr int SQ_BLOCKS = 256;
 
-int make_side_stream(GrcnBwd* b) {
+// b->side = side stream 0 of the device's pool (rgp_core.hip pool_stream; `create`: not inside a stream capture) + the plan's events
+int make_side_stream(GrcnBwd* b, bool create) {
   if (b->side) return RGP_OK;
-  RGP_HIP(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&b->ev_fork, &b->ev_bn, &b->ev_join, &b->ev_wfork, &b->ev_wjoin})
-    RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  RGP_TRY(pool_stream(0, create, &b->side));
+  if (b->side && !b->ev_fork)
+    for (hipEvent_t* e : {&b->ev_fork, &b->ev_bn, &b->ev_join, &b->ev_wfork, &b->ev_wjoin})
+      RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   return RGP_OK;
 }
 
@@ -135,10 +136,11 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   // the graph (two parallel branches) -- provided the side stream exists already: streams are not created during a capture
   const bool persistent = sizeof(T) == 2 && seq_persistent_ok(g) && dev_knob("RGP_SEQ", 1);
   const bool stepwise = ext_dy && g->bwd_step_ev && !persistent && mark;
-  const bool side_ok = (mark || b->side != nullptr) && dev_knob("RGP_BWD_FORK", 1);
+  RGP_TRY(make_side_stream(b, mark));
+  const bool side_ok = b->side != nullptr && dev_knob("RGP_BWD_FORK", 1);
   const bool fork = g->fold_head && !ext_dy && side_ok;
   const bool wfork = side_ok && dev_knob("RGP_BWD_FORK", 1) != 2;
-  if (side_ok) RGP_TRY(make_side_stream(b));
+
 
   // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
   // slices of one flat buffer (engine.py: flat_grads), else one per tensor
@@ -629,8 +631,9 @@ int grcn_bwd_fork_fold(rgp_grcn* g, hipStream_t s, hipStream_t* sc) {
   *sc = s;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
-  if (!g->fold_head || (capturing && !b->side) || !dev_knob("RGP_BWD_FORK", 1)) return RGP_OK;
-  RGP_TRY(make_side_stream(b));
+  if (!g->fold_head || !dev_knob("RGP_BWD_FORK", 1)) return RGP_OK;
+  RGP_TRY(make_side_stream(b, !capturing));
+  if (!b->side) return RGP_OK;
   RGP_HIP(hipEventRecord(b->ev_fork, s));
   RGP_HIP(hipStreamWaitEvent(b->side, b->ev_fork, 0));
   *sc = b->side;

@@ -249,16 +249,18 @@ struct PackBatch {
 // A stream of a plan's own for work its main chain does not wait for (weight gradients beside the data-gradient chain ...):
 // fork(s, i, &sc) puts the side stream behind everything queued on s (event i) and hands it out -- or s itself while s is
 // being captured and the side stream does not exist yet; join(s) makes s wait for the side stream to drain.  Made on first use.
+int pool_stream(int i, bool create, hipStream_t* out);      // rgp_core.hip: side stream i (0 .. 2) of the current device, or null
 struct SideStream {
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr;                                // pool stream 0 (shared, not owned)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
   int fork(hipStream_t s, int i, hipStream_t* sc) {
     *sc = s;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = !(hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone);
-    if ((capturing && !side) || !dev_knob("RGP_SIDE_STREAM", 1)) return RGP_OK;
-    if (!side) {
-      RGP_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    if (!dev_knob("RGP_SIDE_STREAM", 1)) return RGP_OK;
+    RGP_TRY(pool_stream(0, !capturing, &side));
+    if (!side) return RGP_OK;
+    if (!ev_join) {
       for (hipEvent_t* e : {&ev[0], &ev[1], &ev[2], &ev[3], &ev_join}) RGP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     RGP_HIP(hipEventRecord(ev[i], s));
@@ -267,16 +269,13 @@ struct SideStream {
     return RGP_OK;
   }
   int join(hipStream_t s) {
-    if (!side) return RGP_OK;
+    if (!side || !ev_join) return RGP_OK;
     RGP_HIP(hipEventRecord(ev_join, side));
     RGP_HIP(hipStreamWaitEvent(s, ev_join, 0));
     return RGP_OK;
   }
   ~SideStream() {
-    if (side) {
-      (void)hipStreamDestroy(side);
-      for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
-    }
+    if (ev_join) for (hipEvent_t e : {ev[0], ev[1], ev[2], ev[3], ev_join}) (void)hipEventDestroy(e);
   }
 };
 
