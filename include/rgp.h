@@ -17,10 +17,11 @@
  *    void*); a plan may be used from one stream at a time.  Training plans (and the
  *    cascade's forward) run independent parts of a call -- weight gradients beside the
  *    data-gradient chain, the cascade's two cells one time step apart -- on streams of
- *    the plan's own, forked behind `stream` and joined into it before the call returns:
- *    to the caller the call is ordered on `stream` as if it ran there alone.  The same
- *    holds inside a stream capture (the forks become branches of the graph once the
- *    plan's streams exist, i.e. after one eager call; before that the call is serial);
+ *    the library's own (three per device, shared by every plan of the process), forked
+ *    behind `stream` and joined into it before the call returns: to the caller the call
+ *    is ordered on `stream` as if it ran there alone.  The same holds inside a stream
+ *    capture (the forks become branches of the graph once the library's streams exist,
+ *    i.e. after one eager call; before that the call is serial);
  *  - layouts are the reference's: c3d_input [B,T,1024,7,7], maps [B,T,49,49],
  *    conv filters HWIO / DHWIO, transposed-conv filters [kh,kw,out,in];
  *  - dtype selects the MFMA operand type of the contractions (RGP_BF16:
