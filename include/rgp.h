@@ -21,7 +21,9 @@
  *    behind `stream` and joined into it before the call returns: to the caller the call
  *    is ordered on `stream` as if it ran there alone.  The same holds inside a stream
  *    capture (the forks become branches of the graph once the library's streams exist,
- *    i.e. after one eager call; before that the call is serial);
+ *    i.e. after one eager call; before that the call is serial).  Because those streams
+ *    are shared, they join a capture for its duration: while one host thread captures
+ *    calls of this library, no other thread may issue training calls on that device;
  *  - layouts are the reference's: c3d_input [B,T,1024,7,7], maps [B,T,49,49],
  *    conv filters HWIO / DHWIO, transposed-conv filters [kh,kw,out,in];
  *  - dtype selects the MFMA operand type of the contractions (RGP_BF16:
