@@ -148,8 +148,12 @@ namespace {
 int seq_persistent(rgp_grcn* g, hipStream_t s) {
   const int B = g->B, T_ = g->T, S = g->S;
   const size_t st = (size_t)B * 49 * S;
-  RGP_HIP(hipMemsetAsync(g->ws + g->hall.off, 0, st * 4, s));                 // h_0 = 0 (gaze_grcn.py:262)
-  RGP_HIP(hipMemsetAsync(g->ws + g->seq_cnt.off, 0, g->seq_cnt.bytes, s));     // phase counters: zeroed EVERY call
+  {
+    ZeroBatch z(s);
+    RGP_TRY(z.add(g->ws + g->hall.off, st * 4));                             // h_0 = 0 (gaze_grcn.py:262)
+    RGP_TRY(z.add(g->ws + g->seq_cnt.off, g->seq_cnt.bytes));                // phase counters: zeroed EVERY call
+    RGP_TRY(z.flush());
+  }
   SeqParams p;
   p.w_zr = (const bf16_t*)(g->ws + g->gzr.w_off);
   p.w_c = (const bf16_t*)(g->ws + g->gc.w_off);

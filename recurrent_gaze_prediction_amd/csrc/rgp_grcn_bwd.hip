@@ -142,8 +142,9 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
   const bool wfork = side_ok && dev_knob("RGP_BWD_FORK", 1) != 2;
 
 
-  // zero the gradients that are accumulated with atomics: one memset when the caller's gradient tensors are the
-  // slices of one flat buffer (engine.py: flat_grads), else one per tensor
+  // zero the gradients that are accumulated with atomics: one region when the caller's gradient tensors are the
+  // slices of one flat buffer (engine.py: flat_grads), else one per tensor -- all clears of the call in ONE launch (ZeroBatch)
+  ZeroBatch zb(s);
   {
     struct Z { const float* q; size_t n; };
     const Z z[] = {{gr->proj_c3d_W, (size_t)1024 * P}, {gr->proj_c3d_b, (size_t)P},
@@ -163,22 +164,28 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     for (const Z& e : z) owned += e.n;
     for (const Z& e : rest) { all_lo = std::min(all_lo, e.q); all_hi = std::max(all_hi, e.q + e.n); owned += e.n; }
     if ((size_t)(all_hi - all_lo) == owned) {
-      RGP_HIP(hipMemsetAsync((void*)all_lo, 0, owned * 4, s));
+      RGP_TRY(zb.add((void*)all_lo, owned * 4));
     } else {
-      for (const Z& e : z) RGP_HIP(hipMemsetAsync((void*)e.q, 0, e.n * 4, s));
+      for (const Z& e : z) RGP_TRY(zb.add((void*)e.q, e.n * 4));
     }
   }
-  RGP_HIP(hipMemsetAsync(ws + b->dE.off, 0, (size_t)P * sizeof(T), s));                    // dE's zero row
-  if (!g->fold_head) RGP_HIP(hipMemsetAsync(ws + b->dgp.off, 0, b->dgp.bytes, s));      // (the folded path overwrites dgp)
+  RGP_TRY(zb.add(ws + b->dE.off, (size_t)P * sizeof(T)));                                  // dE's zero row
+  if (!g->fold_head) RGP_TRY(zb.add(ws + b->dgp.off, b->dgp.bytes));                     // (the folded path overwrites dgp)
+  // (buffers that only one later kernel of this call adds into: cleared here with the rest, in the one launch)
+  if (g->fold_head && !ext_dy) RGP_TRY(zb.add(ws + b->dkf.off, b->dkf.bytes));           // dK: the wgrad's atomics
+  if (persistent) RGP_TRY(zb.add(ws + b->bptt_cnt.off, b->bptt_cnt.bytes));             // phase counters: zeroed EVERY call
+  if (ext_dy) {                                                                          // (the unused head's gradients)
+    RGP_TRY(zb.add((void*)gr->up_weight3, (size_t)49 * 12 * 32 * 4));
+    RGP_TRY(zb.add((void*)gr->out_W, 12 * 4));
+    RGP_TRY(zb.add((void*)gr->out_b, 4));
+  }
+  RGP_TRY(zb.flush());
 
   if (ext_dy) {
     // the gradient w.r.t. the (batch-normalised) states comes from outside (cascade: the stride-7
     // transposed conv above the bottom cell); the head of this plan is unused, its gradients are zero
     // (stepwise: frame (b, t) of ext_dy is complete only behind bwd_step_ev[t] -- read in place, step by step, below)
     if (!stepwise) RGP_HIP(hipMemcpyAsync(Fp(b->dy), ext_dy, (size_t)M * S * 4, hipMemcpyDeviceToDevice, s));
-    RGP_HIP(hipMemsetAsync((void*)gr->up_weight3, 0, (size_t)49 * 12 * 32 * 4, s));
-    RGP_HIP(hipMemsetAsync((void*)gr->out_W, 0, 12 * 4, s));
-    RGP_HIP(hipMemsetAsync((void*)gr->out_b, 0, 4, s));
   } else {
   // 1. d loss / d logits, d out_b
   dlogits_kernel<<<F, 256, 0, s>>>(loss_l2 ? logits : probs, labels, Fp(b->dz), Fp(b->frame_sum), 2401, 1.0f / (float)F, loss_l2);
@@ -189,7 +196,6 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     const long long tot = M * HF_PK;
     head_fold_patches_kernel<T><<<(int)std::min<long long>((tot + 255) / 256, 8192), 256, 0, s>>>(Fp(b->dz), Tp(b->pm), M);
     RGP_HIP(hipGetLastError());
-    RGP_HIP(hipMemsetAsync(ws + b->dkf.off, 0, b->dkf.bytes, s));                                // dK: the wgrad's atomics
     {
       WgradParams p = wg_params();
       p.X = Tp(b->pm); p.dY = Tp(g->hbn); p.dW = Fp(b->dkf);
@@ -316,7 +322,6 @@ int backward_impl(rgp_grcn* g, const float* probs, const float* logits, const fl
     RGP_HIP(hipEventRecord(b->grad_ev[0], s));
   }
   if (persistent) {
-    RGP_HIP(hipMemsetAsync(ws + b->bptt_cnt.off, 0, b->bptt_cnt.bytes, s));      // phase counters: zeroed EVERY call
     BpttParams q;
     q.w_c = (const bf16_t*)(ws + b->b_c.w_off);
     q.w_zr = (const bf16_t*)(ws + b->b_zr.w_off);

@@ -7,6 +7,33 @@ struct Buf {
   size_t off = 0, bytes = 0;
 };
 
+namespace rgp {
+// host side: add() regions, flush() = one launch (or a plain memset for a single region)
+struct ZeroBatch {
+  ZeroTable t;
+  hipStream_t s;
+  explicit ZeroBatch(hipStream_t stream) : s(stream) { t.n = 0; t.first[0] = 0; }
+  int add(void* p, size_t bytes) {
+    if (bytes == 0) return RGP_OK;
+    if ((bytes & 3) || (((size_t)p) & 3)) return set_err(RGP_EINVAL, "ZeroBatch: region not 4-byte aligned");
+    if (t.n == ZERO_MAX_REGIONS) RGP_TRY(flush());
+    t.ptr[t.n] = p; t.bytes[t.n] = bytes;
+    t.first[t.n + 1] = t.first[t.n] + (int)((bytes + ZERO_BLOCK_BYTES - 1) / ZERO_BLOCK_BYTES);
+    ++t.n;
+    return RGP_OK;
+  }
+  int flush() {
+    if (t.n == 1) RGP_HIP(hipMemsetAsync(t.ptr[0], 0, t.bytes[0], s));
+    else if (t.n > 1) {
+      zero_regions_kernel<<<t.first[t.n], 256, 0, s>>>(t);
+      RGP_HIP(hipGetLastError());
+    }
+    t.n = 0; t.first[0] = 0;
+    return RGP_OK;
+  }
+};
+}  // namespace rgp
+
 struct rgp_grcn {
   // (owner: a cascade plan) step_ev[t] is recorded on the launch stream behind step t of the per-timestep recurrence: lets
   // another stream consume state t while the later steps run (rgp_cascade.hip).  Null = nothing recorded
